@@ -1,0 +1,79 @@
+"""ctypes binding of libhhrl_hip.so (declared in include/hhrl_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a
+call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhhrl_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_long
+_F = C.c_float
+
+# name -> (restype, argtypes); mirrors include/hhrl_hip.h one to one
+SIGNATURES = {
+    "hhrl_version": (_I, []),
+    "hhrl_last_error": (C.c_char_p, []),
+    "hhrl_linear_forward": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "hhrl_linear_backward": (_I, [_P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "hhrl_sum_pool": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
+    "hhrl_broadcast_rows": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
+    "hhrl_copy2d": (_I, [_P, _I, _P, _I, _I, _I, _P]),
+    "hhrl_fill": (_I, [_P, _L, _F, _P]),
+    "hhrl_vae_reparam": (_I, [_P, _P, _P, _I, _I, _P]),
+    "hhrl_vae_elbo": (_I, [_P, _P, _P, _F, _P, _P, _I, _I, _I, _P]),
+    "hhrl_vae_latent_grad": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "hhrl_td3_smooth_action": (_I, [_P, _I, _P, _P, _I, _I, _I, _P]),
+    "hhrl_td3_target_q": (_I, [_P, _P, _P, _F, _P, _I, _P]),
+    "hhrl_twin_mse": (_I, [_P, _P, _P, _F, _P, _P, _P, _I, _P]),
+    "hhrl_lstm_workspace_floats": (_L, [_I, _I, _I, _I]),
+    "hhrl_lstm_forward": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
+    "hhrl_lstm_backward": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "hhrl_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P]),
+    "hhrl_polyak_update": (_I, [_P, _P, _L, _F, _P]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once) and declare every prototype."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "HIP extension not built: %s is missing. Run `python hhrl-vae_amd/build.py` "
+            "(needs hipcc; cross-compiles for gfx950 without a GPU)." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().hhrl_last_error()
+        raise HipError("libhhrl_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def stream_ptr() -> int:
+    """The raw hipStream_t of torch's current stream: kernels are enqueued
+    there so they order with torch's own copies and allocations."""
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,71 @@
+// Shared helpers for the gfx950 kernels of libhhrl_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/hhrl_hip.h"
+
+namespace hhrl {
+
+// Thread-local text of the last error returned through the C ABI.
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Checks the launch that was just enqueued.
+inline int launch_status(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(HHRL_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+  return HHRL_OK;
+}
+
+#define HHRL_REQUIRE(cond, ...) \
+  do {                          \
+    if (!(cond)) return ::hhrl::fail(HHRL_ERR_ARG, __VA_ARGS__); \
+  } while (0)
+
+#define HHRL_TRY(expr)              \
+  do {                              \
+    int _rc = (expr);               \
+    if (_rc != HHRL_OK) return _rc; \
+  } while (0)
+
+constexpr int kWave = 64;  // CDNA wavefront width
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  switch (act) {
+    case HHRL_ACT_RELU: return v > 0.f ? v : 0.f;
+    case HHRL_ACT_TANH: return tanhf(v);
+    case HHRL_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    default: return v;
+  }
+}
+
+// d act / d pre-activation, written in terms of the activation OUTPUT y.
+__device__ __forceinline__ float act_grad_from_output(float y, int act) {
+  switch (act) {
+    case HHRL_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    case HHRL_ACT_TANH: return 1.f - y * y;
+    case HHRL_ACT_SIGMOID: return y * (1.f - y);
+    default: return 1.f;
+  }
+}
+
+inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Internal GEMM front door (gemm.hip):  C[i][j] (op)= sum_k A(i,k) * B(k,j)
+//   A(i,k) = A[i*a_si + k*a_sk],  B(k,j) = B[k*b_sk + j*b_sj]
+// mode 0: C = act(acc + bias[j]); mode 1: C = act(C + acc + bias[j]);
+// mode 2: atomicAdd(C, acc) with the reduction split over workgroups.
+int gemm(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj, float* C, long ldc,
+         int M, int N, int K, const float* bias, int act, int mode, hipStream_t st);
+
+}  // namespace hhrl

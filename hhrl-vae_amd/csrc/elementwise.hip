@@ -1,0 +1,252 @@
+// Elementwise / reduction kernels of the VAE loss and the TD3 update rule,
+// and the flat-buffer optimiser kernels.  All are HBM-bound streams.
+#include "common.h"
+
+#include <cmath>
+
+namespace hhrl {
+
+// ---------------------------------------------------------------- VAE
+__global__ void vae_reparam_kernel(const float* __restrict__ ml, const float* __restrict__ eps, float* z, int B, int g) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * g) return;
+  const int b = idx / g, j = idx % g;
+  const float mean = ml[b * 2 * g + j], lv = ml[b * 2 * g + g + j];
+  z[idx] = mean + eps[idx] * expf(0.5f * lv);
+}
+
+// One pass over the B*N reconstruction terms and the B*g KL terms.  Each
+// thread accumulates privately, a wave reduces with shuffles, a workgroup
+// with LDS, and one atomic per workgroup lands in *loss.
+__global__ __launch_bounds__(256) void vae_elbo_kernel(const float* __restrict__ decoded, const float* __restrict__ data,
+                                                       const float* __restrict__ ml, float recon_scale, float* loss,
+                                                       float* d_decoded, int BN, int Bg, int g) {
+  __shared__ float red[4];
+  const int stride = gridDim.x * blockDim.x;
+  const int t0 = blockIdx.x * blockDim.x + threadIdx.x;
+  float s = 0.f;
+  for (int i = t0; i < BN; i += stride) {
+    const float d = decoded[i] - data[2 * i + 1];
+    s += recon_scale * d * d;
+    d_decoded[i] = 2.f * recon_scale * d;
+  }
+  for (int i = t0; i < Bg; i += stride) {
+    const int b = i / g, j = i % g;
+    const float mean = ml[b * 2 * g + j], lv = ml[b * 2 * g + g + j];
+    s += -0.5f * (1.f + lv - mean * mean - expf(lv));
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(loss, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ void vae_latent_grad_kernel(const float* __restrict__ dz, const float* __restrict__ ml,
+                                       const float* __restrict__ eps, float* d_ml, int B, int g) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * g) return;
+  const int b = idx / g, j = idx % g;
+  const float mean = ml[b * 2 * g + j], lv = ml[b * 2 * g + g + j];
+  const float d = dz[idx];
+  d_ml[b * 2 * g + j] = d + mean;
+  d_ml[b * 2 * g + g + j] = d * eps[idx] * 0.5f * expf(0.5f * lv) + 0.5f * (expf(lv) - 1.f);
+}
+
+// ---------------------------------------------------------------- TD3
+__global__ void td3_smooth_action_kernel(const float* __restrict__ pi, int ldp, const float* __restrict__ eps,
+                                         float* out, int ldo, int B, int a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * a) return;
+  const int b = idx / a, j = idx % a;
+  float n = 0.2f * eps[idx];
+  n = fminf(fmaxf(n, -0.5f), 0.5f);
+  const float v = pi[(long)b * ldp + j] + n;
+  out[(long)b * ldo + j] = fminf(fmaxf(v, -1.f), 1.f);
+}
+
+__global__ void td3_target_q_kernel(const float* __restrict__ q1, const float* __restrict__ q2,
+                                    const float* __restrict__ r, float gamma, float* y, int B) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < B) y[idx] = r[idx] + gamma * fminf(q1[idx], q2[idx]);
+}
+
+__global__ __launch_bounds__(256) void twin_mse_kernel(const float* __restrict__ q1, const float* __restrict__ q2,
+                                                       const float* __restrict__ y, float inv_n, float* loss,
+                                                       float* dq1, float* dq2, int B) {
+  __shared__ float red[2][4];
+  const int stride = gridDim.x * blockDim.x;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += stride) {
+    const float d1 = q1[i] - y[i], d2 = q2[i] - y[i];
+    s1 += d1 * d1;
+    s2 += d2 * d2;
+    dq1[i] = 2.f * inv_n * d1;
+    dq2[i] = 2.f * inv_n * d2;
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsafeAtomicAdd(&loss[0], inv_n * (red[0][0] + red[0][1] + red[0][2] + red[0][3]));
+    unsafeAtomicAdd(&loss[1], inv_n * (red[1][0] + red[1][1] + red[1][2] + red[1][3]));
+  }
+}
+
+// ---------------------------------------------------------- optimiser
+// One coalesced pass: reads p,g,m,v (16 B each), writes p,m,v: 28 B / parameter.
+struct AdamK {
+  float step_size, beta1, beta2, one_minus_b1, one_minus_b2, bc2_sqrt, eps, gscale;
+};
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamK& k) {
+  g *= k.gscale;
+  m = m + k.one_minus_b1 * (g - m);                 // exp_avg.lerp_(grad, 1-beta1)
+  v = v * k.beta2 + k.one_minus_b2 * g * g;         // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1-beta2)
+  const float denom = sqrtf(v) / k.bc2_sqrt + k.eps;
+  p = p - k.step_size * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* __restrict__ g, float* m, float* v, long n, AdamK k) {
+  const long n4 = n >> 2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 P = reinterpret_cast<float4*>(p)[i];
+    const float4 G = reinterpret_cast<const float4*>(g)[i];
+    float4 Mo = reinterpret_cast<float4*>(m)[i];
+    float4 V = reinterpret_cast<float4*>(v)[i];
+    adam_one(P.x, G.x, Mo.x, V.x, k);
+    adam_one(P.y, G.y, Mo.y, V.y, k);
+    adam_one(P.z, G.z, Mo.z, V.z, k);
+    adam_one(P.w, G.w, Mo.w, V.w, k);
+    reinterpret_cast<float4*>(p)[i] = P;
+    reinterpret_cast<float4*>(m)[i] = Mo;
+    reinterpret_cast<float4*>(v)[i] = V;
+  }
+  const long tail = n4 << 2;
+  const long i = tail + (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) adam_one(p[i], g[i], m[i], v[i], k);
+}
+
+__global__ __launch_bounds__(256) void adam_scalar_kernel(float* p, const float* __restrict__ g, float* m, float* v, long n, AdamK k) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) adam_one(p[i], g[i], m[i], v[i], k);
+}
+
+__global__ __launch_bounds__(256) void polyak_kernel(float* t, const float* __restrict__ p, long n, float tau, int vec) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  const float om = 1.f - tau;
+  if (vec) {
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+      const float4 P = reinterpret_cast<const float4*>(p)[i];
+      float4 T = reinterpret_cast<float4*>(t)[i];
+      T.x = tau * P.x + om * T.x;
+      T.y = tau * P.y + om * T.y;
+      T.z = tau * P.z + om * T.z;
+      T.w = tau * P.w + om * T.w;
+      reinterpret_cast<float4*>(t)[i] = T;
+    }
+    const long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) t[i] = tau * p[i] + om * t[i];
+  } else {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) t[i] = tau * p[i] + om * t[i];
+  }
+}
+
+static inline bool aligned16(const void* a) { return (reinterpret_cast<uintptr_t>(a) & 15) == 0; }
+static inline int stream_grid(long n_items) {
+  long b = (n_items + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > 2048) b = 2048;      // 256 CUs x 8 resident workgroups; grid-stride beyond
+  return (int)b;
+}
+
+}  // namespace hhrl
+
+using namespace hhrl;
+
+extern "C" {
+
+int hhrl_vae_reparam(const float* ml, const float* eps, float* z, int B, int g, void* stream) {
+  HHRL_REQUIRE(ml && eps && z, "vae_reparam: null pointer");
+  HHRL_REQUIRE(B > 0 && g > 0, "vae_reparam: bad shape B=%d g=%d", B, g);
+  hipLaunchKernelGGL(vae_reparam_kernel, dim3(ceil_div((long)B * g, 256)), dim3(256), 0, as_stream(stream), ml, eps, z, B, g);
+  return launch_status("vae_reparam_kernel");
+}
+
+int hhrl_vae_elbo(const float* decoded, const float* data, const float* ml, float recon_scale, float* loss,
+                  float* d_decoded, int B, int N, int g, void* stream) {
+  HHRL_REQUIRE(decoded && data && ml && loss && d_decoded, "vae_elbo: null pointer");
+  HHRL_REQUIRE(B > 0 && N > 0 && g > 0, "vae_elbo: bad shape B=%d N=%d g=%d", B, N, g);
+  const long bn = (long)B * N;
+  HHRL_REQUIRE(bn < (1L << 30), "vae_elbo: B*N too large");
+  const int grid = stream_grid(bn > (long)B * g ? bn : (long)B * g);
+  hipLaunchKernelGGL(vae_elbo_kernel, dim3(grid), dim3(256), 0, as_stream(stream), decoded, data, ml, recon_scale, loss,
+                     d_decoded, (int)bn, B * g, g);
+  return launch_status("vae_elbo_kernel");
+}
+
+int hhrl_vae_latent_grad(const float* dz, const float* ml, const float* eps, float* d_ml, int B, int g, void* stream) {
+  HHRL_REQUIRE(dz && ml && eps && d_ml, "vae_latent_grad: null pointer");
+  HHRL_REQUIRE(B > 0 && g > 0, "vae_latent_grad: bad shape B=%d g=%d", B, g);
+  hipLaunchKernelGGL(vae_latent_grad_kernel, dim3(ceil_div((long)B * g, 256)), dim3(256), 0, as_stream(stream), dz, ml, eps, d_ml, B, g);
+  return launch_status("vae_latent_grad_kernel");
+}
+
+int hhrl_td3_smooth_action(const float* pi, int ldp, const float* eps, float* out, int ldo, int B, int a, void* stream) {
+  HHRL_REQUIRE(pi && eps && out, "td3_smooth_action: null pointer");
+  HHRL_REQUIRE(B > 0 && a > 0 && ldp >= a && ldo >= a, "td3_smooth_action: bad shape B=%d a=%d ldp=%d ldo=%d", B, a, ldp, ldo);
+  hipLaunchKernelGGL(td3_smooth_action_kernel, dim3(ceil_div((long)B * a, 256)), dim3(256), 0, as_stream(stream), pi, ldp, eps, out, ldo, B, a);
+  return launch_status("td3_smooth_action_kernel");
+}
+
+int hhrl_td3_target_q(const float* q1, const float* q2, const float* r, float gamma, float* y, int B, void* stream) {
+  HHRL_REQUIRE(q1 && q2 && r && y, "td3_target_q: null pointer");
+  HHRL_REQUIRE(B > 0, "td3_target_q: B=%d", B);
+  hipLaunchKernelGGL(td3_target_q_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, as_stream(stream), q1, q2, r, gamma, y, B);
+  return launch_status("td3_target_q_kernel");
+}
+
+int hhrl_twin_mse(const float* q1, const float* q2, const float* y, float inv_n, float* loss, float* dq1, float* dq2,
+                  int B, void* stream) {
+  HHRL_REQUIRE(q1 && q2 && y && loss && dq1 && dq2, "twin_mse: null pointer");
+  HHRL_REQUIRE(B > 0, "twin_mse: B=%d", B);
+  hipLaunchKernelGGL(twin_mse_kernel, dim3(stream_grid(B)), dim3(256), 0, as_stream(stream), q1, q2, y, inv_n, loss, dq1, dq2, B);
+  return launch_status("twin_mse_kernel");
+}
+
+int hhrl_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                   int step, float grad_scale, void* stream) {
+  HHRL_REQUIRE(p && g && m && v, "adam_step: null pointer");
+  HHRL_REQUIRE(n > 0 && step >= 1, "adam_step: n=%ld step=%d", n, step);
+  // Bias corrections in double on the host, as torch computes them.
+  const double bc1 = 1.0 - std::pow((double)beta1, step);
+  const double bc2 = 1.0 - std::pow((double)beta2, step);
+  AdamK k;
+  k.step_size = (float)((double)lr / bc1);
+  k.beta1 = beta1;
+  k.beta2 = beta2;
+  k.one_minus_b1 = (float)(1.0 - (double)beta1);
+  k.one_minus_b2 = (float)(1.0 - (double)beta2);
+  k.bc2_sqrt = (float)std::sqrt(bc2);
+  k.eps = eps;
+  k.gscale = grad_scale;
+  hipStream_t st = as_stream(stream);
+  if (aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v)) {
+    hipLaunchKernelGGL(adam_kernel, dim3(stream_grid((n + 3) / 4)), dim3(256), 0, st, p, g, m, v, n, k);
+  } else {
+    hipLaunchKernelGGL(adam_scalar_kernel, dim3(stream_grid(n)), dim3(256), 0, st, p, g, m, v, n, k);
+  }
+  return launch_status("adam_kernel");
+}
+
+int hhrl_polyak_update(float* target, const float* p, long n, float tau, void* stream) {
+  HHRL_REQUIRE(target && p, "polyak_update: null pointer");
+  HHRL_REQUIRE(n > 0, "polyak_update: n=%ld", n);
+  const int vec = aligned16(target) && aligned16(p);
+  hipLaunchKernelGGL(polyak_kernel, dim3(stream_grid(vec ? (n + 3) / 4 : n)), dim3(256), 0, as_stream(stream), target, p, n, tau, vec);
+  return launch_status("polyak_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,153 @@
+// Dense layer forward/backward and the strided data-movement kernels.
+#include "common.h"
+
+namespace hhrl {
+
+static thread_local char g_err[512];
+char* err_buf() { return g_err; }
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+// dy <- dy * act'(y) in place, and db[col] += sum over rows.  A workgroup
+// covers CW columns x (256/CW) rows per pass over a slab of rows; CW is the
+// power of two >= min(N,64) so narrow layers still use every lane.
+__global__ __launch_bounds__(256) void act_grad_colsum_kernel(const float* __restrict__ y, int ldy, float* dy, int lddy,
+                                                              float* db, int M, int N, int act, int cw,
+                                                              int rows_per_block) {
+  __shared__ float red[256];
+  const int t = threadIdx.x;
+  const int tx = t % cw, ty = t / cw, rp = 256 / cw;
+  const int col = blockIdx.x * cw + tx;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(M, r0 + rows_per_block);
+  float s = 0.f;
+  if (col < N) {
+    for (int r = r0 + ty; r < r1; r += rp) {
+      float gr = dy[(long)r * lddy + col];
+      if (act != HHRL_ACT_NONE) {
+        gr *= act_grad_from_output(y[(long)r * ldy + col], act);
+        dy[(long)r * lddy + col] = gr;
+      }
+      s += gr;
+    }
+  }
+  if (db == nullptr) return;
+  red[t] = s;
+  __syncthreads();
+  for (int h = rp >> 1; h > 0; h >>= 1) {
+    if (ty < h) red[t] += red[t + h * cw];
+    __syncthreads();
+  }
+  if (ty == 0 && col < N) unsafeAtomicAdd(&db[col], red[t]);
+}
+
+__global__ void sum_pool_kernel(const float* __restrict__ in, int ldi, float* out, int ldo, int B, int N, int C) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * C) return;
+  const int b = idx / C, c = idx % C;
+  const float* p = in + (long)b * N * ldi + c;
+  float s = 0.f;
+  for (int n = 0; n < N; ++n) s += p[(long)n * ldi];
+  out[(long)b * ldo + c] = s;
+}
+
+__global__ void broadcast_rows_kernel(const float* __restrict__ in, int ldi, float* out, int ldo, int B, int N, int C) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * N * C) return;
+  const int c = idx % C;
+  const long row = idx / C;
+  out[row * ldo + c] = in[(row / N) * ldi + c];
+}
+
+__global__ void copy2d_kernel(const float* __restrict__ in, int ldi, float* out, int ldo, int M, int C) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)M * C) return;
+  const int c = idx % C;
+  const long r = idx / C;
+  out[r * ldo + c] = in[r * ldi + c];
+}
+
+__global__ void fill_kernel(float* p, long n, float v) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < n) p[idx] = v;
+}
+
+static int valid_act(int act) { return act >= HHRL_ACT_NONE && act <= HHRL_ACT_SIGMOID; }
+
+}  // namespace hhrl
+
+using namespace hhrl;
+
+extern "C" {
+
+int hhrl_version(void) { return 100; }
+const char* hhrl_last_error(void) { return err_buf(); }
+
+int hhrl_linear_forward(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int K,
+                        int N, int act, int accumulate, void* stream) {
+  HHRL_REQUIRE(x && w && y, "linear_forward: null pointer");
+  HHRL_REQUIRE(M > 0 && K > 0 && N > 0, "linear_forward: non-positive size M=%d K=%d N=%d", M, K, N);
+  HHRL_REQUIRE(ldx >= K && ldy >= N, "linear_forward: leading dimension too small (ldx=%d K=%d ldy=%d N=%d)", ldx, K, ldy, N);
+  HHRL_REQUIRE(valid_act(act), "linear_forward: bad activation %d", act);
+  return gemm(x, ldx, 1, w, 1, K, y, ldy, M, N, K, b, act, accumulate ? 1 : 0, as_stream(stream));
+}
+
+int hhrl_linear_backward(const float* x, int ldx, const float* w, const float* y, int ldy, float* dy, int lddy,
+                         float* dx, int lddx, int dx_accumulate, float* dw, float* db, int M, int K, int N, int act,
+                         void* stream) {
+  HHRL_REQUIRE(dy && w, "linear_backward: null pointer");
+  HHRL_REQUIRE(M > 0 && K > 0 && N > 0, "linear_backward: non-positive size M=%d K=%d N=%d", M, K, N);
+  HHRL_REQUIRE(valid_act(act), "linear_backward: bad activation %d", act);
+  HHRL_REQUIRE(act == HHRL_ACT_NONE || (y && ldy >= N), "linear_backward: activation gradient needs y");
+  HHRL_REQUIRE(lddy >= N, "linear_backward: lddy=%d < N=%d", lddy, N);
+  HHRL_REQUIRE(!dx || lddx >= K, "linear_backward: lddx=%d < K=%d", lddx, K);
+  HHRL_REQUIRE(!dw || (x && ldx >= K), "linear_backward: dW needs x with ldx >= K");
+  hipStream_t st = as_stream(stream);
+  if (act != HHRL_ACT_NONE || db) {
+    int cw = 64;
+    while (cw > 1 && cw / 2 >= N) cw >>= 1;
+    const int rp = 256 / cw;
+    int rows_per_block = rp * 16;
+    dim3 grid(ceil_div(N, cw), ceil_div(M, rows_per_block));
+    hipLaunchKernelGGL(act_grad_colsum_kernel, grid, dim3(256), 0, st, y, ldy, dy, lddy, db, M, N, act, cw,
+                       rows_per_block);
+    HHRL_TRY(launch_status("act_grad_colsum_kernel"));
+  }
+  if (dx) HHRL_TRY(gemm(dy, lddy, 1, w, K, 1, dx, lddx, M, K, N, nullptr, HHRL_ACT_NONE, dx_accumulate ? 1 : 0, st));
+  if (dw) HHRL_TRY(gemm(dy, 1, lddy, x, ldx, 1, dw, K, N, K, M, nullptr, HHRL_ACT_NONE, 2, st));
+  return HHRL_OK;
+}
+
+int hhrl_sum_pool(const float* in, int ldi, float* out, int ldo, int B, int N, int C, void* stream) {
+  HHRL_REQUIRE(in && out, "sum_pool: null pointer");
+  HHRL_REQUIRE(B > 0 && N > 0 && C > 0 && ldi >= C && ldo >= C, "sum_pool: bad shape B=%d N=%d C=%d ldi=%d ldo=%d", B, N, C, ldi, ldo);
+  hipLaunchKernelGGL(sum_pool_kernel, dim3(ceil_div((long)B * C, 256)), dim3(256), 0, as_stream(stream), in, ldi, out, ldo, B, N, C);
+  return launch_status("sum_pool_kernel");
+}
+
+int hhrl_broadcast_rows(const float* in, int ldi, float* out, int ldo, int B, int N, int C, void* stream) {
+  HHRL_REQUIRE(in && out, "broadcast_rows: null pointer");
+  HHRL_REQUIRE(B > 0 && N > 0 && C > 0 && ldi >= C && ldo >= C, "broadcast_rows: bad shape B=%d N=%d C=%d ldi=%d ldo=%d", B, N, C, ldi, ldo);
+  hipLaunchKernelGGL(broadcast_rows_kernel, dim3(ceil_div((long)B * N * C, 256)), dim3(256), 0, as_stream(stream), in, ldi, out, ldo, B, N, C);
+  return launch_status("broadcast_rows_kernel");
+}
+
+int hhrl_copy2d(const float* in, int ldi, float* out, int ldo, int M, int C, void* stream) {
+  HHRL_REQUIRE(in && out, "copy2d: null pointer");
+  HHRL_REQUIRE(M > 0 && C > 0 && ldi >= C && ldo >= C, "copy2d: bad shape M=%d C=%d ldi=%d ldo=%d", M, C, ldi, ldo);
+  hipLaunchKernelGGL(copy2d_kernel, dim3(ceil_div((long)M * C, 256)), dim3(256), 0, as_stream(stream), in, ldi, out, ldo, M, C);
+  return launch_status("copy2d_kernel");
+}
+
+int hhrl_fill(float* p, long n, float value, void* stream) {
+  HHRL_REQUIRE(p && n > 0, "fill: null pointer or n <= 0");
+  hipLaunchKernelGGL(fill_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), p, n, value);
+  return launch_status("fill_kernel");
+}
+
+}  // extern "C"

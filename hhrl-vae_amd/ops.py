@@ -1,0 +1,100 @@
+"""Thin, allocation-free wrappers that enqueue the HIP kernels on torch's
+current stream.  Operands are raw device addresses (ints) plus leading
+dimensions, so column slices of wider buffers are addressed directly."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, check
+from .flat import FlatBuffer
+
+
+def P(t: torch.Tensor, col: int = 0) -> int:
+    """Device address of element `col` of a contiguous fp32 tensor."""
+    return t.data_ptr() + 4 * col
+
+
+def dev_empty(*shape, device) -> torch.Tensor:
+    return torch.empty(*shape, dtype=torch.float32, device=device)
+
+
+def dev_zeros(*shape, device) -> torch.Tensor:
+    return torch.zeros(*shape, dtype=torch.float32, device=device)
+
+
+class Lin:
+    """One dense layer bound to its slices of the flat parameter / gradient
+    buffers (nn.Linear layout: weight [out, in], bias [out])."""
+
+    def __init__(self, params: FlatBuffer, grads: Optional[FlatBuffer], name: str, act: int = ACT_NONE):
+        self.name = name
+        self.N, self.K = params.layout.shapes[name + ".weight"]
+        self.act = act
+        self.w = params.ptr(name + ".weight")
+        self.b = params.ptr(name + ".bias")
+        self.gw = grads.ptr(name + ".weight") if grads is not None else None
+        self.gb = grads.ptr(name + ".bias") if grads is not None else None
+        self._lib = _lib.load()
+
+    def fwd(self, x: int, ldx: int, y: int, ldy: int, M: int, accumulate: int = 0) -> None:
+        check(self._lib.hhrl_linear_forward(x, ldx, self.w, self.b, y, ldy, M, self.K, self.N, self.act,
+                                            accumulate, _lib.stream_ptr()))
+
+    def bwd(self, x: Optional[int], ldx: int, y: Optional[int], ldy: int, dy: int, lddy: int,
+            dx: Optional[int], lddx: int, M: int, dx_accumulate: int = 0, param_grads: bool = True) -> None:
+        gw = self.gw if param_grads else None
+        gb = self.gb if param_grads else None
+        check(self._lib.hhrl_linear_backward(x, ldx, self.w, y, ldy, dy, lddy, dx, lddx, dx_accumulate,
+                                             gw, gb, M, self.K, self.N, self.act, _lib.stream_ptr()))
+
+
+LSTM_KEYS = ["lstm_layer.weight_ih_l0", "lstm_layer.weight_hh_l0", "lstm_layer.bias_ih_l0", "lstm_layer.bias_hh_l0",
+             "lstm_layer.weight_ih_l0_reverse", "lstm_layer.weight_hh_l0_reverse",
+             "lstm_layer.bias_ih_l0_reverse", "lstm_layer.bias_hh_l0_reverse", "fc.weight", "fc.bias"]
+
+
+class BiLstm:
+    """The reference's LSTM module (algorithm.py:141-156) bound to its slices
+    of the flat buffers; `prefix` is e.g. 'lstm.' or 'lstm2.'."""
+
+    def __init__(self, params: FlatBuffer, grads: Optional[FlatBuffer], prefix: str, obs_dim: int, T: int, hid: int):
+        self.o, self.T, self.H = obs_dim, T, hid
+        self._lib = _lib.load()
+        self.params = (C.c_void_p * 10)(*[params.ptr(prefix + k) for k in LSTM_KEYS])
+        self.grads = (C.c_void_p * 10)(*[grads.ptr(prefix + k) for k in LSTM_KEYS]) if grads is not None else None
+
+    def workspace(self, B: int, device) -> torch.Tensor:
+        n = self._lib.hhrl_lstm_workspace_floats(B, self.T, self.o, self.H)
+        return dev_empty(n, device=device)
+
+    def fwd(self, obs: int, ldobs: int, out: int, ldo: int, ws: torch.Tensor, B: int) -> None:
+        check(self._lib.hhrl_lstm_forward(obs, ldobs, self.params, out, ldo, ws.data_ptr(), B, self.T, self.o, self.H,
+                                          _lib.stream_ptr()))
+
+    def bwd(self, d_out: int, lddo: int, ws: torch.Tensor, B: int) -> None:
+        check(self._lib.hhrl_lstm_backward(self.params, d_out, lddo, self.grads, ws.data_ptr(), B, self.T, self.o,
+                                           self.H, _lib.stream_ptr()))
+
+
+def sum_pool(inp: int, ldi: int, out: int, ldo: int, B: int, N: int, Cc: int) -> None:
+    check(_lib.load().hhrl_sum_pool(inp, ldi, out, ldo, B, N, Cc, _lib.stream_ptr()))
+
+
+def broadcast_rows(inp: int, ldi: int, out: int, ldo: int, B: int, N: int, Cc: int) -> None:
+    check(_lib.load().hhrl_broadcast_rows(inp, ldi, out, ldo, B, N, Cc, _lib.stream_ptr()))
+
+
+def copy2d(inp: int, ldi: int, out: int, ldo: int, M: int, Cc: int) -> None:
+    check(_lib.load().hhrl_copy2d(inp, ldi, out, ldo, M, Cc, _lib.stream_ptr()))
+
+
+def fill(p: int, n: int, value: float) -> None:
+    check(_lib.load().hhrl_fill(p, n, value, _lib.stream_ptr()))
+
+
+def polyak(target: FlatBuffer, net: FlatBuffer, tau: float) -> None:
+    check(_lib.load().hhrl_polyak_update(target.base_ptr, net.base_ptr, net.layout.size, tau, _lib.stream_ptr()))

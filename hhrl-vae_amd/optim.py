@@ -1,0 +1,87 @@
+"""Adam on flat buffers + the StepLR rule, interoperable with torch's
+optimizer `state_dict` format (the reference saves `optimizer.state_dict()`,
+algorithm.py:132, 333, 335 ...)."""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from . import _lib
+from .flat import FlatBuffer, Layout
+
+
+class FlatAdam:
+    """torch.optim.Adam defaults (betas (0.9, 0.999), eps 1e-8, no weight
+    decay, no amsgrad) as one fused kernel launch over the flat buffer."""
+
+    beta1, beta2, eps = 0.9, 0.999, 1e-8
+
+    def __init__(self, params: FlatBuffer, lr: float):
+        dev = params.data.device
+        self.p = params
+        self.g = FlatBuffer(params.layout, dev)
+        self.m = FlatBuffer(params.layout, dev)
+        self.v = FlatBuffer(params.layout, dev)
+        self.lr = float(lr)
+        self.base_lr = float(lr)
+        self.step_count = 0
+        self._lib = _lib.load()
+
+    def zero_grad(self) -> None:
+        self.g.data.zero_()
+
+    def step(self, grad_scale: float = 1.0) -> None:
+        self.step_count += 1
+        _lib.check(self._lib.hhrl_adam_step(
+            self.p.base_ptr, self.g.base_ptr, self.m.base_ptr, self.v.base_ptr, self.p.layout.size,
+            self.lr, self.beta1, self.beta2, self.eps, self.step_count, float(grad_scale), _lib.stream_ptr()))
+
+    # -- torch-format round trip ------------------------------------------
+    def state_dict(self) -> dict:
+        names = self.p.layout.names
+        state = {}
+        if self.step_count > 0:
+            for i, n in enumerate(names):
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.m[n].detach().cpu().clone(),
+                            "exp_avg_sq": self.v[n].detach().cpu().clone()}
+        group = {"lr": self.lr, "betas": (self.beta1, self.beta2), "eps": self.eps, "weight_decay": 0,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
+                 "differentiable": False, "fused": None, "decoupled_weight_decay": False,
+                 "initial_lr": self.base_lr, "params": list(range(len(names)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd: dict) -> None:
+        names = self.p.layout.names
+        group = sd["param_groups"][0]
+        if len(group["params"]) != len(names):
+            raise ValueError("optimizer state has %d params, network has %d" % (len(group["params"]), len(names)))
+        self.lr = float(group["lr"])
+        self.base_lr = float(group.get("initial_lr", group["lr"]))
+        self.m.data.zero_()
+        self.v.data.zero_()
+        self.step_count = 0
+        for i, n in enumerate(names):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            self.m[n].copy_(torch.as_tensor(st["exp_avg"], dtype=torch.float32))
+            self.v[n].copy_(torch.as_tensor(st["exp_avg_sq"], dtype=torch.float32))
+            self.step_count = max(self.step_count, int(float(st["step"])))
+
+
+class StepLR:
+    """lr = base_lr * gamma ** (calls // step_size)  — torch's StepLR with the
+    reference's gamma = 0.5 (algorithm.py:260-261).  Computed on the host; the
+    value reaches the Adam kernel as a scalar argument."""
+
+    def __init__(self, opt: FlatAdam, step_size: int, gamma: float = 0.5):
+        self.opt = opt
+        self.step_size = int(step_size)
+        self.gamma = float(gamma)
+        self.epoch = 0
+
+    def step(self) -> None:
+        self.epoch += 1
+        self.opt.lr = self.opt.base_lr * self.gamma ** (self.epoch // self.step_size)

@@ -1,0 +1,286 @@
+"""DeepSets VAE trainer on MI355X — the reference's `Encoder`
+(algorithm.py:76-138) with the same call surface: learn / encode / decode /
+save / load, `goal_dim`, and `state_dict` key names.
+
+Every arithmetic step runs in hand-written HIP kernels (libhhrl_hip.so);
+torch is used for device memory and host<->device copies only.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, check
+from .flat import FlatBuffer, Layout
+from .ops import Lin, P
+from .optim import FlatAdam
+
+ENC_KEYS = ["phi.0", "phi.2", "rho.0", "rho.2", "to_mean", "to_logvar"]
+DEC_KEYS = ["decoder.0", "decoder.2", "loc", "func.0", "func.2", "func.4"]
+
+
+def vae_shapes(goal_dim: int, car_info_dim: int = 2) -> List[Tuple[str, Tuple[int, ...]]]:
+    """Parameter names/shapes in `Encoder.parameters()` order.  Layer widths:
+    DeepSetEncoder(rho_dim=64, phi_dim=32, hidden_dim=128) at algorithm.py:80,
+    DeepSetDecoder(hidden_dim=128) at algorithm.py:51-66."""
+    dims = {
+        "encoder.phi.0": (16, car_info_dim), "encoder.phi.2": (32, 16),
+        "encoder.rho.0": (128, 32), "encoder.rho.2": (64, 128),
+        "encoder.to_mean": (goal_dim, 64), "encoder.to_logvar": (goal_dim, 64),
+        "decoder.decoder.0": (128, goal_dim), "decoder.decoder.2": (32, 128),
+        "decoder.loc": (32, 1),
+        "decoder.func.0": (128, 64), "decoder.func.2": (32, 128), "decoder.func.4": (1, 32),
+    }
+    out = []
+    for k in ["encoder." + e for e in ENC_KEYS] + ["decoder." + d for d in DEC_KEYS]:
+        out.append((k + ".weight", dims[k]))
+        out.append((k + ".bias", (dims[k][0],)))
+    return out
+
+
+def _default_init(layout: Layout, gen: torch.Generator) -> Dict[str, torch.Tensor]:
+    """nn.Linear's default: U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weight and bias."""
+    out = {}
+    fan_in = 1
+    for name, shp in layout.shapes.items():
+        if name.endswith(".weight"):
+            fan_in = shp[1]
+        k = 1.0 / (fan_in ** 0.5)
+        out[name] = (torch.rand(shp, generator=gen) * 2 - 1) * k
+    return out
+
+
+class _Work:
+    """Activation / gradient buffers for one (B, N) batch shape."""
+
+    def __init__(self, B: int, N: int, g: int, dev):
+        M = B * N
+        e = lambda *s: ops.dev_empty(*s, device=dev)
+        self.B, self.N, self.M = B, N, M
+        self.h1, self.h2 = e(M, 16), e(M, 32)
+        self.pooled, self.r1, self.r2 = e(B, 32), e(B, 128), e(B, 64)
+        self.ml, self.z = e(B, 2 * g), e(B, g)
+        self.d1, self.d2 = e(B, 128), e(B, 32)
+        self.cat, self.f1, self.f2, self.dec = e(M, 64), e(M, 128), e(M, 32), e(M, 1)
+        # gradients
+        self.d_dec, self.d_f2, self.d_f1, self.d_cat = e(M, 1), e(M, 32), e(M, 128), e(M, 64)
+        self.d_d2, self.d_d1, self.d_z = e(B, 32), e(B, 128), e(B, g)
+        self.d_ml, self.d_r2, self.d_r1, self.d_pooled = e(B, 2 * g), e(B, 64), e(B, 128), e(B, 32)
+        self.d_h2, self.d_h1 = e(M, 32), e(M, 16)
+
+
+class Encoder:
+    """Drop-in for the reference's `Encoder(car_info_dim, goal_dim)`.
+
+    Extras that the reference does not have (all optional):
+      * `learn(data, eps=...)` takes the reparameterisation noise explicitly
+        (the reference draws it with `randn_like`, algorithm.py:89);
+      * `learn(..., sync=False)` returns the loss as a 0-dim device tensor
+        instead of forcing a device->host sync per step (algorithm.py:107);
+      * `data` may already be a device tensor [B, N, 2];
+      * `group` / `world_size`: data-parallel training, one flat gradient
+        all-reduce per step.
+    """
+
+    def __init__(self, car_info_dim: int, goal_dim: int, device: Optional[str] = None, seed: Optional[int] = None,
+                 group=None):
+        if car_info_dim != 2:
+            raise ValueError("the lane state is (location, speed): car_info_dim must be 2 (algorithm.py:94-95)")
+        if not torch.cuda.is_available():
+            raise RuntimeError("hhrl_vae_amd needs an AMD GPU (no CPU fallback)")
+        self._lib = _lib.load()
+        self.goal_dim = int(goal_dim)
+        self.device = torch.device(device or "cuda")
+        self.layout = Layout(vae_shapes(self.goal_dim))
+        self.params = FlatBuffer(self.layout, self.device)
+        gen = torch.Generator().manual_seed(3407 if seed is None else seed)
+        self.params.load(_default_init(self.layout, gen))
+        self.opt = FlatAdam(self.params, lr=0.001)                      # algorithm.py:83
+        g = self.opt.g
+        L = lambda name, act=ACT_NONE: Lin(self.params, g, name, act)
+        self.phi0, self.phi2 = L("encoder.phi.0", ACT_RELU), L("encoder.phi.2")
+        self.rho0, self.rho2 = L("encoder.rho.0", ACT_RELU), L("encoder.rho.2")
+        self.to_mean, self.to_logvar = L("encoder.to_mean"), L("encoder.to_logvar")
+        self.dec0, self.dec2 = L("decoder.decoder.0", ACT_RELU), L("decoder.decoder.2")
+        self.loc = L("decoder.loc")
+        self.func0, self.func2 = L("decoder.func.0", ACT_RELU), L("decoder.func.2", ACT_RELU)
+        self.func4 = L("decoder.func.4", ACT_SIGMOID)
+        self._work: Dict[Tuple[int, int], _Work] = {}
+        self._loss = ops.dev_zeros(1, device=self.device)
+        self._rng = torch.Generator(device=self.device)
+        self._rng.manual_seed(3407)
+        self.group = group
+        self.world_size = 1
+        if group is not None:
+            import torch.distributed as dist
+            self.world_size = dist.get_world_size(group)
+
+    # ------------------------------------------------------------ helpers
+    def _ws(self, B: int, N: int) -> _Work:
+        w = self._work.get((B, N))
+        if w is None:
+            if len(self._work) > 64:          # ragged bucket sizes: keep the cache bounded
+                self._work.clear()
+            w = self._work[(B, N)] = _Work(B, N, self.goal_dim, self.device)
+        return w
+
+    def _to_device(self, data) -> torch.Tensor:
+        if isinstance(data, torch.Tensor):
+            t = data.to(device=self.device, dtype=torch.float32)
+        else:
+            t = torch.as_tensor(np.asarray(data, dtype=np.float32)).to(self.device)     # algorithm.py:93
+        return t.contiguous()
+
+    # ------------------------------------------------------------ forward
+    def _encode_fwd(self, x: torch.Tensor, w: _Work) -> None:
+        """DeepSetEncoder.forward (algorithm.py:40-47) on [B*N, 2] rows -> w.ml = mean||logvar."""
+        B, N, M, g = w.B, w.N, w.M, self.goal_dim
+        self.phi0.fwd(P(x), 2, P(w.h1), 16, M)
+        self.phi2.fwd(P(w.h1), 16, P(w.h2), 32, M)
+        ops.sum_pool(P(w.h2), 32, P(w.pooled), 32, B, N, 32)
+        self.rho0.fwd(P(w.pooled), 32, P(w.r1), 128, B)
+        self.rho2.fwd(P(w.r1), 128, P(w.r2), 64, B)
+        self.to_mean.fwd(P(w.r2), 64, P(w.ml), 2 * g, B)
+        self.to_logvar.fwd(P(w.r2), 64, P(w.ml, g), 2 * g, B)
+
+    def _decode_fwd(self, x_loc: int, ld_loc: int, w: _Work) -> None:
+        """DeepSetDecoder.forward (algorithm.py:68-73).  The latent branch is
+        evaluated once per lane and broadcast to its N cars, which equals the
+        reference's repeat-then-MLP (algorithm.py:101) value for value."""
+        B, N, M, g = w.B, w.N, w.M, self.goal_dim
+        self.dec0.fwd(P(w.z), g, P(w.d1), 128, B)
+        self.dec2.fwd(P(w.d1), 128, P(w.d2), 32, B)
+        ops.broadcast_rows(P(w.d2), 32, P(w.cat), 64, B, N, 32)
+        self.loc.fwd(x_loc, ld_loc, P(w.cat, 32), 64, M)
+        self.func0.fwd(P(w.cat), 64, P(w.f1), 128, M)
+        self.func2.fwd(P(w.f1), 128, P(w.f2), 32, M)
+        self.func4.fwd(P(w.f2), 32, P(w.dec), 1, M)
+
+    # ------------------------------------------------------------ training
+    def loss_and_grads(self, data, eps=None, recon_count: Optional[int] = None) -> torch.Tensor:
+        """Forward + ELBO + backward into the flat gradient buffer (zeroed
+        first).  Returns the loss as a 0-dim device tensor (no sync).
+        recon_count: divisor of the squared-error sum (default B*N; the global
+        element count on a data-parallel shard)."""
+        x = self._to_device(data)
+        if x.dim() != 3 or x.shape[-1] != 2 or x.shape[0] == 0 or x.shape[1] == 0:
+            raise ValueError("data must be [B, N, 2] with B, N >= 1, got %s" % (tuple(x.shape),))
+        B, N = int(x.shape[0]), int(x.shape[1])
+        g = self.goal_dim
+        if eps is None:
+            eps = torch.randn((B, g), generator=self._rng, device=self.device, dtype=torch.float32)
+        else:
+            eps = torch.as_tensor(eps, dtype=torch.float32).to(self.device).contiguous()
+            if tuple(eps.shape) != (B, g):
+                raise ValueError("eps must be [%d, %d], got %s" % (B, g, tuple(eps.shape)))
+        w = self._ws(B, N)
+        M = w.M
+        st = _lib.stream_ptr()
+        lib = self._lib
+        self.opt.zero_grad()                                            # algorithm.py:98
+        self._loss.zero_()
+        self._encode_fwd(x, w)                                          # :99
+        check(lib.hhrl_vae_reparam(P(w.ml), P(eps), P(w.z), B, g, st))  # :100
+        self._decode_fwd(P(x), 2, w)                                    # :101
+        scale = 1.0 / float(recon_count if recon_count is not None else M)
+        check(lib.hhrl_vae_elbo(P(w.dec), P(x), P(w.ml), scale, P(self._loss), P(w.d_dec), B, N, g, st))  # :102-104
+        # backward (:105)
+        self.func4.bwd(P(w.f2), 32, P(w.dec), 1, P(w.d_dec), 1, P(w.d_f2), 32, M)
+        self.func2.bwd(P(w.f1), 128, P(w.f2), 32, P(w.d_f2), 32, P(w.d_f1), 128, M)
+        self.func0.bwd(P(w.cat), 64, P(w.f1), 128, P(w.d_f1), 128, P(w.d_cat), 64, M)
+        self.loc.bwd(P(x), 2, None, 0, P(w.d_cat, 32), 64, None, 0, M)
+        ops.sum_pool(P(w.d_cat), 64, P(w.d_d2), 32, B, N, 32)
+        self.dec2.bwd(P(w.d1), 128, None, 0, P(w.d_d2), 32, P(w.d_d1), 128, B)
+        self.dec0.bwd(P(w.z), g, P(w.d1), 128, P(w.d_d1), 128, P(w.d_z), g, B)
+        check(lib.hhrl_vae_latent_grad(P(w.d_z), P(w.ml), P(eps), P(w.d_ml), B, g, st))
+        self.to_mean.bwd(P(w.r2), 64, None, 0, P(w.d_ml), 2 * g, P(w.d_r2), 64, B)
+        self.to_logvar.bwd(P(w.r2), 64, None, 0, P(w.d_ml, g), 2 * g, P(w.d_r2), 64, B, dx_accumulate=1)
+        self.rho2.bwd(P(w.r1), 128, None, 0, P(w.d_r2), 64, P(w.d_r1), 128, B)
+        self.rho0.bwd(P(w.pooled), 32, P(w.r1), 128, P(w.d_r1), 128, P(w.d_pooled), 32, B)
+        ops.broadcast_rows(P(w.d_pooled), 32, P(w.d_h2), 32, B, N, 32)
+        self.phi2.bwd(P(w.h1), 16, None, 0, P(w.d_h2), 32, P(w.d_h1), 16, M)
+        self.phi0.bwd(P(x), 2, P(w.h1), 16, P(w.d_h1), 16, None, 0, M)
+        self._keep = (x, eps)           # keep inputs alive until the stream has consumed them
+        return self._loss[0]
+
+    def learn(self, data, eps=None, sync: bool = True):
+        """Encoder.learn (algorithm.py:92-107): one Adam step on one batch of
+        lanes that all hold N cars.  Returns the loss (float, or a device
+        scalar when sync=False)."""
+        if self.group is None:
+            loss = self.loss_and_grads(data, eps)
+        else:
+            import torch.distributed as dist
+            x = self._to_device(data)
+            cnt = torch.tensor([float(x.shape[0] * x.shape[1])], device=self.device)
+            dist.all_reduce(cnt, group=self.group)
+            loss = self.loss_and_grads(x, eps, recon_count=int(cnt.item()))
+            dist.all_reduce(self.opt.g.data, group=self.group)          # one flat bucket, SUM
+            loss = loss.clone()
+            dist.all_reduce(loss, group=self.group)
+        self.opt.step()                                                 # :106
+        return float(loss.item()) if sync else loss.clone()
+
+    # ------------------------------------------------------------ inference
+    def encode(self, x) -> np.ndarray:
+        """Encoder.encode (algorithm.py:109-116): one lane [N, 2] -> mean||logvar [2g]."""
+        if len(x) == 0:
+            return np.zeros((self.goal_dim * 2))
+        xt = self._to_device(x)
+        if xt.dim() != 2 or xt.shape[1] != 2:
+            raise ValueError("encode expects one lane [N, 2]")
+        w = self._ws(1, int(xt.shape[0]))
+        self._encode_fwd(xt, w)
+        return w.ml[0].cpu().numpy()
+
+    def encode_batch(self, lanes: torch.Tensor) -> torch.Tensor:
+        """[B, N, 2] lanes with a common car count -> [B, 2g] on the device."""
+        xt = self._to_device(lanes)
+        w = self._ws(int(xt.shape[0]), int(xt.shape[1]))
+        self._encode_fwd(xt, w)
+        return w.ml.clone()
+
+    def decode(self, goal, loc, eps=None) -> np.ndarray:
+        """Encoder.decode (algorithm.py:121-127): samples z from (mean, logvar)
+        and decodes the speed at `loc`; shapes [2g] and [1] -> [1]."""
+        g = self.goal_dim
+        goal_t = torch.as_tensor(np.asarray(goal, dtype=np.float32)).reshape(1, 2 * g).to(self.device)
+        loc_t = torch.as_tensor(np.asarray(loc, dtype=np.float32)).reshape(1, 1).to(self.device)
+        if eps is None:
+            eps_t = torch.randn((1, g), generator=self._rng, device=self.device, dtype=torch.float32)
+        else:
+            eps_t = torch.as_tensor(np.asarray(eps, dtype=np.float32)).reshape(1, g).to(self.device)
+        w = self._ws(1, 1)
+        w.ml.copy_(goal_t)
+        check(self._lib.hhrl_vae_reparam(P(w.ml), P(eps_t), P(w.z), 1, g, _lib.stream_ptr()))
+        self._decode_fwd(P(loc_t), 1, w)
+        return w.dec[0].cpu().numpy()
+
+    # ------------------------------------------------------------ checkpoints
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return self.params.state_dict()
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        self.params.load(sd)
+
+    def grads(self) -> Dict[str, torch.Tensor]:
+        return self.opt.g.state_dict()
+
+    def save(self, filename: str) -> None:
+        """Same three files as algorithm.py:129-132, same key names."""
+        sd = self.params.state_dict()
+        torch.save({k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}, filename + "_enc")
+        torch.save({k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")}, filename + "_dec")
+        torch.save(self.opt.state_dict(), filename + "_encoder_optimizer")
+
+    def load(self, filename: str) -> None:
+        """algorithm.py:134-138."""
+        enc = torch.load(filename + "_enc", weights_only=True)
+        dec = torch.load(filename + "_dec", weights_only=True)
+        sd = {"encoder." + k: v for k, v in enc.items()}
+        sd.update({"decoder." + k: v for k, v in dec.items()})
+        self.params.load(sd)
+        self.opt.load_state_dict(torch.load(filename + "_encoder_optimizer", weights_only=True))

@@ -1,0 +1,146 @@
+/* hhrl_hip.h — C ABI of libhhrl_hip.so, the MI355X (gfx950) kernels behind the
+ * HHRL-VAE learning path.
+ *
+ * The reference has no FFI: its boundary is the Python class surface of
+ * src/algorithm.py.  Each entry point below names the reference statements it
+ * replaces (file:line under the reference's src/).  A Python host binds these
+ * with ctypes (see hhrl-vae_amd/_lib.py); no torch type crosses the boundary.
+ *
+ * Conventions
+ *   - every pointer is DEVICE memory, fp32, row-major, borrowed for the call;
+ *   - "ld*" is a leading dimension in ELEMENTS (row stride), so callers can
+ *     read from / write into column slices of wider buffers (concatenations
+ *     are never materialised by a copy);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *     all work is enqueued asynchronously on it, nothing synchronises;
+ *   - return value: HHRL_OK, or an error code; hhrl_last_error() returns a
+ *     thread-local message for the last non-zero return;
+ *   - weights use nn.Linear layout W[out][in]; LSTM gate order is i,f,g,o.
+ */
+#ifndef HHRL_HIP_H
+#define HHRL_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HHRL_OK 0
+#define HHRL_ERR_ARG 1 /* null pointer, non-positive size, bad enum, ld too small */
+#define HHRL_ERR_HIP 2 /* a HIP runtime call or kernel launch failed */
+
+#define HHRL_ACT_NONE 0
+#define HHRL_ACT_RELU 1
+#define HHRL_ACT_TANH 2
+#define HHRL_ACT_SIGMOID 3
+
+/* Library identification / diagnostics. */
+int hhrl_version(void);
+const char* hhrl_last_error(void);
+
+/* ------------------------------------------------------------------ layers
+ * y[M,N] = act( (accumulate ? y : 0) + x[M,K] * w[N,K]^T + b[N] )
+ * Replaces nn.Linear + ReLU/Tanh/Sigmoid: algorithm.py:21-25, 27-31, 37-38,
+ * 53-66, 169-171, 177-179, 199-206, 214-220, 1197-1199, 1225-1232.
+ * b may be NULL.  fp32 MFMA (v_mfma_f32_32x32x2_f32), LDS-staged tiles. */
+int hhrl_linear_forward(const float* x, int ldx, const float* w, const float* b,
+                        float* y, int ldy, int M, int K, int N, int act,
+                        int accumulate, void* stream);
+
+/* Backward of the layer above (autograd of the same lines; loss.backward()
+ * at algorithm.py:105, 311, 319, 513, 530, 806, 823, 1151, 1159, 1348, 1357).
+ *   dy  : in  dL/dy (post-activation), out dL/d(pre-activation), in place;
+ *   y   : the forward output (needed when act != NONE, else may be NULL);
+ *   dx  : dL/dx, written (dx_accumulate=0) or added to; NULL to skip;
+ *   dw,db: ADDED to (torch .grad semantics; the caller zeroes them); either
+ *          may be NULL to skip.  dW is reduced over M with a split reduction
+ *          and float atomics. */
+int hhrl_linear_backward(const float* x, int ldx, const float* w,
+                         const float* y, int ldy, float* dy, int lddy,
+                         float* dx, int lddx, int dx_accumulate,
+                         float* dw, float* db, int M, int K, int N, int act,
+                         void* stream);
+
+/* ------------------------------------------------------------ data movement
+ * out[b, c] = sum_n in[(b*N+n), c]          (torch.sum(x, dim=-2), algorithm.py:42;
+ *                                            also the gradient of the latent repeat, :101) */
+int hhrl_sum_pool(const float* in, int ldi, float* out, int ldo, int B, int N, int C, void* stream);
+/* out[(b*N+n), c] = in[b, c]                (z.unsqueeze(-2).repeat(1,N,1), algorithm.py:101;
+ *                                            also the gradient of the sum-pool, :42) */
+int hhrl_broadcast_rows(const float* in, int ldi, float* out, int ldo, int B, int N, int C, void* stream);
+/* out[m, c] = in[m, c] for a [M,C] block    (torch.cat pieces, algorithm.py:71, 212, 383, 652, 1207, 1238) */
+int hhrl_copy2d(const float* in, int ldi, float* out, int ldo, int M, int C, void* stream);
+/* p[i] = value */
+int hhrl_fill(float* p, long n, float value, void* stream);
+
+/* --------------------------------------------------------------------- VAE
+ * z = mean + eps * exp(0.5*logvar)          (Encoder.reparameterize, algorithm.py:87-90;
+ *                                            eps is supplied by the caller instead of randn_like)
+ * ml is [B, 2g] = mean || logvar. */
+int hhrl_vae_reparam(const float* ml, const float* eps, float* z, int B, int g, void* stream);
+
+/* ELBO and its gradient at the decoder output (algorithm.py:102-104):
+ *   loss += recon_scale * sum((decoded - v)^2) - 0.5*sum(1 + logvar - mean^2 - exp(logvar))
+ *   d_decoded = 2*recon_scale*(decoded - v)
+ * data is [B*N, 2] (col 1 = v); recon_scale = 1/(B*N) on one device, 1/(global B*N)
+ * on a data-parallel shard.  *loss must be zeroed by the caller (it is added to).
+ * Wave-level shuffle reductions, one atomic per workgroup. */
+int hhrl_vae_elbo(const float* decoded, const float* data, const float* ml, float recon_scale,
+                  float* loss, float* d_decoded, int B, int N, int g, void* stream);
+
+/* Gradient at the encoder heads (autograd of algorithm.py:87-90, 103):
+ *   d_mean   = dz + mean
+ *   d_logvar = dz*eps*0.5*exp(0.5*logvar) + 0.5*(exp(logvar) - 1)       -> d_ml [B,2g] */
+int hhrl_vae_latent_grad(const float* dz, const float* ml, const float* eps, float* d_ml,
+                         int B, int g, void* stream);
+
+/* --------------------------------------------------------------------- TD3
+ * Target-policy smoothing (algorithm.py:295-296, 494-497, 786-791, 1135-1136, 1330-1331):
+ *   out = clamp(pi + clamp(0.2*eps, -0.5, 0.5), -1, 1);  eps ~ N(0,1) from the caller. */
+int hhrl_td3_smooth_action(const float* pi, int ldp, const float* eps, float* out, int ldo,
+                           int B, int a, void* stream);
+/* y = r + gamma*min(q1,q2)                  (algorithm.py:300-301, 502-503, 795-796, 1140-1141, 1336-1337) */
+int hhrl_td3_target_q(const float* q1, const float* q2, const float* r, float gamma, float* y,
+                      int B, void* stream);
+/* Twin critic loss and its gradient (F.mse_loss x2, algorithm.py:307, 509, 802, 1147, 1344):
+ *   loss[0] += inv_n*sum((q1-y)^2); loss[1] += inv_n*sum((q2-y)^2);
+ *   dq1 = 2*inv_n*(q1-y); dq2 = 2*inv_n*(q2-y).   loss[2] zeroed by the caller. */
+int hhrl_twin_mse(const float* q1, const float* q2, const float* y, float inv_n, float* loss,
+                  float* dq1, float* dq2, int B, void* stream);
+
+/* -------------------------------------------------------------------- LSTM
+ * Bidirectional one-layer LSTM over a window of T steps, last time index only,
+ * followed by Linear(2H -> H)             (LSTM.forward, algorithm.py:152-156).
+ * The forward direction runs T steps; the reverse direction contributes its
+ * first step only (input x[:, T-1], zero state), as r_out[:, -1, :] does.
+ * params: 10 device pointers in state_dict order:
+ *   weight_ih_l0[4H,o] weight_hh_l0[4H,H] bias_ih_l0[4H] bias_hh_l0[4H]
+ *   weight_ih_l0_reverse weight_hh_l0_reverse bias_ih_l0_reverse bias_hh_l0_reverse
+ *   fc.weight[H,2H] fc.bias[H]
+ * obs is [B, T*o] with leading dimension ldobs (a column slice of a replay
+ * row block); out [B,H] with leading dimension ldo; ws is a workspace of
+ * hhrl_lstm_workspace_floats(B,T,o,H) floats that must stay untouched until
+ * the matching backward has run. */
+long hhrl_lstm_workspace_floats(int B, int T, int o, int H);
+int hhrl_lstm_forward(const float* obs, int ldobs, const float* const* params, float* out, int ldo,
+                      float* ws, int B, int T, int o, int H, void* stream);
+/* BPTT of the above.  d_out [B,H] (ld lddo) is dL/d(out).  grads: 10 device
+ * pointers laid out like params; gradients are ADDED (weight_hh_l0_reverse
+ * receives nothing: its input state is zero).  No gradient w.r.t. obs. */
+int hhrl_lstm_backward(const float* const* params, const float* d_out, int lddo,
+                       float* const* grads, float* ws, int B, int T, int o, int H, void* stream);
+
+/* --------------------------------------------------------------- optimiser
+ * torch.optim.Adam.step with default betas/eps on one flat buffer
+ * (algorithm.py:83, 106, 259, 266, 312, 320 ...): bias-corrected, no weight
+ * decay, no amsgrad.  `step` is the 1-based step count AFTER this update;
+ * lr comes from the host-side StepLR rule.  g is multiplied by grad_scale
+ * first (1.0 normally; 1/world for an averaged all-reduce). */
+int hhrl_adam_step(float* p, const float* g, float* m, float* v, long n, float lr,
+                   float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+/* target = tau*p + (1-tau)*target          (algorithm.py:323-326, 534-539, 827-834, 1163-1166, 1361-1364) */
+int hhrl_polyak_update(float* target, const float* p, long n, float tau, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HHRL_HIP_H */

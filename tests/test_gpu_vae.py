@@ -1,0 +1,153 @@
+"""VAE training path on the GPU (through the C ABI) against the golden vectors
+recorded from the reference and, at BASELINE sizes, against the CPU oracle on
+the same inputs.  Bar: fp32, rtol 1e-4 (plus an absolute floor of 2e-6 of each
+tensor's largest magnitude, since fp32 sums in a different order cannot meet a
+pure rtol at values near zero)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gen
+import hhrl_oracle as O
+from golden_util import assert_close, load_case, sub
+from test_gpu_kernels import scaled_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _enc(g, init):
+    from hhrl_vae_amd.algorithm import Encoder
+    e = Encoder(2, g)
+    e.load_state_dict(init)
+    return e
+
+
+def _np(sd):
+    return {k: v.numpy() for k, v in sd.items()}
+
+
+def dict_close(name, got, want, **kw):
+    assert set(want) <= set(got)
+    for k in want:
+        scaled_close(name + "/" + k, got[k], want[k], **kw)
+
+
+@pytest.mark.parametrize("g", [2, 4, 8, 16])
+def test_vae_golden_steps(g):
+    fx = load_case("vae_g%d" % g)
+    e = _enc(g, sub(fx, "init"))
+    for step in range(3):
+        loss = e.learn(fx["step%d/x" % step].tolist(), eps=fx["step%d/eps" % step])
+        assert_close("loss%d" % step, loss, fx["step%d/loss" % step], rtol=1e-4, atol=0)
+        if step == 0 and g == 4:
+            dict_close("grad0", _np(e.grads()), sub(fx, "step0/grad"))
+            dict_close("param0", _np(e.state_dict()), sub(fx, "step0/param"))
+    dict_close("final", _np(e.state_dict()), sub(fx, "final/param"))
+    if g == 4:
+        dict_close("exp_avg", _np(e.opt.m.state_dict()), sub(fx, "final/exp_avg"))
+        dict_close("exp_avg_sq", _np(e.opt.v.state_dict()), sub(fx, "final/exp_avg_sq"))
+
+
+@pytest.mark.parametrize("tag", ["edge_n1", "edge_b1", "edge_n59"])
+def test_vae_golden_ragged(tag):
+    """One car per lane, one lane per batch, and the longest lane the state
+    log can hold (59 cars)."""
+    fx = load_case("vae_g4")
+    e = _enc(4, sub(fx, "final/param"))
+    loss = e.loss_and_grads(fx[tag + "/x"], fx[tag + "/eps"])
+    assert_close("loss", float(loss), fx[tag + "/loss"], rtol=1e-4, atol=0)
+    dict_close("grad", _np(e.grads()), sub(fx, tag + "/grad"))
+
+
+def test_vae_golden_encode_decode():
+    fx = load_case("vae_g4")
+    e = _enc(4, sub(fx, "final/param"))
+    scaled_close("encode", e.encode(fx["encode/x"].tolist()), fx["encode/out"])
+    empty = e.encode([])
+    assert empty.shape == (8,) and not empty.any()
+    scaled_close("decode", e.decode(fx["decode/goal"], fx["decode/loc"], eps=fx["decode/eps"]), fx["decode/out"])
+
+
+def test_vae_golden_batch_loop():
+    """The chunked, shuffled one-pass training loop of VAE_train.py:55-69."""
+    from hhrl_vae_amd.vae_train import chunk_dataset, train_one_pass
+    fx = load_case("vae_loop_g2")
+    dataset = {k: v.tolist() for k, v in sub(fx, "bucket").items()}
+    chunks = chunk_dataset(dataset, int(fx["batch_size"]))
+    order = fx["order"].tolist()
+    assert [len(chunks[i]) for i in order] == fx["chunk_sizes"].tolist()
+    e = _enc(2, sub(fx, "init"))
+    losses = train_one_pass(e, [chunks[i] for i in order], eps_list=[fx["eps%d" % s] for s in range(len(order))])
+    assert_close("losses", losses, fx["losses"], rtol=1e-4, atol=0)
+    dict_close("final", _np(e.state_dict()), sub(fx, "final/param"))
+
+
+@pytest.mark.parametrize("B,N,g", [(4096, 7, 4), (4096, 30, 4), (1000, 3, 16)])
+def test_vae_full_size_vs_oracle(B, N, g):
+    """BASELINE batch sizes: loss, every gradient and the parameters after two
+    Adam steps against the CPU oracle on identical inputs."""
+    shapes = O.vae_param_shapes(g)
+    init = gen.gen_state(shapes, 1234 + g)
+    oracle = O.VAE({k: torch.from_numpy(v) for k, v in init.items()}, g)
+    e = _enc(g, init)
+    for step in range(2):
+        x = gen.gen_lanes(B, N, 77 + step)
+        eps = torch.randn(B, g, generator=torch.Generator().manual_seed(3407 + step))
+        want = oracle.learn(x, eps)
+        got = e.learn(torch.from_numpy(x).cuda(), eps=eps)
+        assert_close("loss", got, want, rtol=1e-4, atol=0)
+        dict_close("grad%d" % step, _np(e.grads()), {k: v.numpy() for k, v in oracle.grads.items()}, atol_rel=1e-5)
+    dict_close("param", _np(e.state_dict()), {k: v.detach().numpy() for k, v in oracle.p.items()})
+
+
+def test_vae_properties_full_size():
+    """Size-independent properties at B=4096: (a) permuting the lanes of a
+    batch (with their noise rows) leaves loss and gradients unchanged up to
+    summation order; (b) permuting the cars inside a lane does too (DeepSets
+    invariance of the encoder + per-car decoder); (c) gradients of two half
+    batches scaled by the global count add up to the full-batch gradient."""
+    g, B, N = 4, 4096, 7
+    init = gen.gen_state(O.vae_param_shapes(g), 99)
+    e = _enc(g, init)
+    x = torch.from_numpy(gen.gen_lanes(B, N, 5)).cuda()
+    eps = torch.randn(B, g, generator=torch.Generator().manual_seed(1)).cuda()
+    l0 = float(e.loss_and_grads(x, eps))
+    g0 = _np(e.grads())
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(2)).cuda()
+    l1 = float(e.loss_and_grads(x[perm], eps[perm]))
+    assert_close("lane-perm loss", l1, l0, rtol=1e-5, atol=0)
+    dict_close("lane-perm grad", _np(e.grads()), g0, atol_rel=1e-5)
+    cperm = torch.randperm(N, generator=torch.Generator().manual_seed(3)).cuda()
+    l2 = float(e.loss_and_grads(x[:, cperm], eps))
+    assert_close("car-perm loss", l2, l0, rtol=1e-5, atol=0)
+    dict_close("car-perm grad", _np(e.grads()), g0, atol_rel=1e-5)
+    h = B // 2
+    la = float(e.loss_and_grads(x[:h], eps[:h], recon_count=B * N))
+    ga = _np(e.grads())
+    lb = float(e.loss_and_grads(x[h:], eps[h:], recon_count=B * N))
+    gb = _np(e.grads())
+    assert_close("shard loss", la + lb, l0, rtol=1e-5, atol=0)
+    dict_close("shard grad", {k: ga[k] + gb[k] for k in ga}, g0, atol_rel=1e-5)
+
+
+def test_vae_checkpoint_roundtrip(tmp_path):
+    """save/load writes the reference's three files with its key names
+    (algorithm.py:129-138) and restores parameters and Adam state."""
+    fx = load_case("vae_g4")
+    e = _enc(4, sub(fx, "init"))
+    e.learn(fx["step0/x"], eps=fx["step0/eps"])
+    prefix = os.path.join(str(tmp_path), "encoder_dim_4")
+    e.save(prefix)
+    enc_sd = torch.load(prefix + "_enc", weights_only=True)
+    assert list(enc_sd)[:2] == ["phi.0.weight", "phi.0.bias"] and "to_logvar.bias" in enc_sd
+    opt_sd = torch.load(prefix + "_encoder_optimizer", weights_only=True)
+    assert len(opt_sd["param_groups"][0]["params"]) == 24 and float(opt_sd["state"][0]["step"]) == 1.0
+    e2 = _enc(4, sub(fx, "init"))
+    e2.load(prefix)
+    for step in (1, 2):
+        a = e.learn(fx["step%d/x" % step], eps=fx["step%d/eps" % step])
+        b = e2.learn(fx["step%d/x" % step], eps=fx["step%d/eps" % step])
+        assert_close("loss", b, a, rtol=1e-6, atol=0)
+    dict_close("final", _np(e2.state_dict()), sub(fx, "final/param"))
