@@ -17,6 +17,7 @@ _P = C.c_void_p
 _I = C.c_int
 _L = C.c_long
 _F = C.c_float
+_D = C.c_double
 
 # name -> (restype, argtypes); mirrors include/hhrl_hip.h one to one
 SIGNATURES = {
@@ -32,13 +33,13 @@ SIGNATURES = {
     "hhrl_vae_elbo": (_I, [_P, _P, _P, _F, _P, _P, _I, _I, _I, _P]),
     "hhrl_vae_latent_grad": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "hhrl_td3_smooth_action": (_I, [_P, _I, _P, _P, _I, _I, _I, _P]),
-    "hhrl_td3_target_q": (_I, [_P, _P, _P, _F, _P, _I, _P]),
+    "hhrl_td3_target_q": (_I, [_P, _P, _P, _I, _F, _P, _I, _P]),
     "hhrl_twin_mse": (_I, [_P, _P, _P, _F, _P, _P, _P, _I, _P]),
     "hhrl_lstm_workspace_floats": (_L, [_I, _I, _I, _I]),
     "hhrl_lstm_forward": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "hhrl_lstm_backward": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
-    "hhrl_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P]),
-    "hhrl_polyak_update": (_I, [_P, _P, _L, _F, _P]),
+    "hhrl_adam_step": (_I, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _I, _D, _P]),
+    "hhrl_polyak_update": (_I, [_P, _P, _L, _D, _P]),
 }
 
 _lib = None

@@ -65,9 +65,9 @@ __global__ void td3_smooth_action_kernel(const float* __restrict__ pi, int ldp, 
 }
 
 __global__ void td3_target_q_kernel(const float* __restrict__ q1, const float* __restrict__ q2,
-                                    const float* __restrict__ r, float gamma, float* y, int B) {
+                                    const float* __restrict__ r, int ldr, float gamma, float* y, int B) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < B) y[idx] = r[idx] + gamma * fminf(q1[idx], q2[idx]);
+  if (idx < B) y[idx] = r[(long)idx * ldr] + gamma * fminf(q1[idx], q2[idx]);
 }
 
 __global__ __launch_bounds__(256) void twin_mse_kernel(const float* __restrict__ q1, const float* __restrict__ q2,
@@ -133,9 +133,8 @@ __global__ __launch_bounds__(256) void adam_scalar_kernel(float* p, const float*
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) adam_one(p[i], g[i], m[i], v[i], k);
 }
 
-__global__ __launch_bounds__(256) void polyak_kernel(float* t, const float* __restrict__ p, long n, float tau, int vec) {
+__global__ __launch_bounds__(256) void polyak_kernel(float* t, const float* __restrict__ p, long n, float tau, float om, int vec) {
   const long stride = (long)gridDim.x * blockDim.x;
-  const float om = 1.f - tau;
   if (vec) {
     const long n4 = n >> 2;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -201,10 +200,11 @@ int hhrl_td3_smooth_action(const float* pi, int ldp, const float* eps, float* ou
   return launch_status("td3_smooth_action_kernel");
 }
 
-int hhrl_td3_target_q(const float* q1, const float* q2, const float* r, float gamma, float* y, int B, void* stream) {
+int hhrl_td3_target_q(const float* q1, const float* q2, const float* r, int ldr, float gamma, float* y, int B,
+                      void* stream) {
   HHRL_REQUIRE(q1 && q2 && r && y, "td3_target_q: null pointer");
-  HHRL_REQUIRE(B > 0, "td3_target_q: B=%d", B);
-  hipLaunchKernelGGL(td3_target_q_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, as_stream(stream), q1, q2, r, gamma, y, B);
+  HHRL_REQUIRE(B > 0 && ldr >= 1, "td3_target_q: B=%d ldr=%d", B, ldr);
+  hipLaunchKernelGGL(td3_target_q_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, as_stream(stream), q1, q2, r, ldr, gamma, y, B);
   return launch_status("td3_target_q_kernel");
 }
 
@@ -216,22 +216,22 @@ int hhrl_twin_mse(const float* q1, const float* q2, const float* y, float inv_n,
   return launch_status("twin_mse_kernel");
 }
 
-int hhrl_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
-                   int step, float grad_scale, void* stream) {
+int hhrl_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
+                   double eps, int step, double grad_scale, void* stream) {
   HHRL_REQUIRE(p && g && m && v, "adam_step: null pointer");
   HHRL_REQUIRE(n > 0 && step >= 1, "adam_step: n=%ld step=%d", n, step);
   // Bias corrections in double on the host, as torch computes them.
-  const double bc1 = 1.0 - std::pow((double)beta1, step);
-  const double bc2 = 1.0 - std::pow((double)beta2, step);
+  const double bc1 = 1.0 - std::pow(beta1, step);
+  const double bc2 = 1.0 - std::pow(beta2, step);
   AdamK k;
-  k.step_size = (float)((double)lr / bc1);
-  k.beta1 = beta1;
-  k.beta2 = beta2;
-  k.one_minus_b1 = (float)(1.0 - (double)beta1);
-  k.one_minus_b2 = (float)(1.0 - (double)beta2);
+  k.step_size = (float)(lr / bc1);
+  k.beta1 = (float)beta1;
+  k.beta2 = (float)beta2;
+  k.one_minus_b1 = (float)(1.0 - beta1);
+  k.one_minus_b2 = (float)(1.0 - beta2);
   k.bc2_sqrt = (float)std::sqrt(bc2);
-  k.eps = eps;
-  k.gscale = grad_scale;
+  k.eps = (float)eps;
+  k.gscale = (float)grad_scale;
   hipStream_t st = as_stream(stream);
   if (aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v)) {
     hipLaunchKernelGGL(adam_kernel, dim3(stream_grid((n + 3) / 4)), dim3(256), 0, st, p, g, m, v, n, k);
@@ -241,11 +241,12 @@ int hhrl_adam_step(float* p, const float* g, float* m, float* v, long n, float l
   return launch_status("adam_kernel");
 }
 
-int hhrl_polyak_update(float* target, const float* p, long n, float tau, void* stream) {
+int hhrl_polyak_update(float* target, const float* p, long n, double tau, void* stream) {
   HHRL_REQUIRE(target && p, "polyak_update: null pointer");
   HHRL_REQUIRE(n > 0, "polyak_update: n=%ld", n);
   const int vec = aligned16(target) && aligned16(p);
-  hipLaunchKernelGGL(polyak_kernel, dim3(stream_grid(vec ? (n + 3) / 4 : n)), dim3(256), 0, as_stream(stream), target, p, n, tau, vec);
+  hipLaunchKernelGGL(polyak_kernel, dim3(stream_grid(vec ? (n + 3) / 4 : n)), dim3(256), 0, as_stream(stream), target, p, n,
+                     (float)tau, (float)(1.0 - tau), vec);
   return launch_status("polyak_kernel");
 }
 

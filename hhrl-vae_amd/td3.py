@@ -1,0 +1,638 @@
+"""TD3 minibatch updates of the hierarchical agents on MI355X.
+
+One engine (`TD3Learner`) covers every variant of the reference
+(TD3Single, HATD3Double, HATD3, HATD3Triple, ManagerTD3, WorkerTD3): they
+differ only in how many observation streams / actors they have and in the
+replay row layout.  The classes at the bottom keep the reference's constructor
+signatures, attributes and method names.
+
+A sampled minibatch is uploaded ONCE as a [B, row_width] fp32 block; every
+network input is a column slice of that block (pointer + leading dimension),
+and every concatenation the reference builds with torch.cat is a column range
+of a wider activation buffer that producers write into directly.
+"""
+from __future__ import annotations
+
+import copy
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import ACT_NONE, ACT_RELU, ACT_TANH, check
+from .flat import FlatBuffer, Layout
+from .ops import BiLstm, Lin, P
+from .optim import FlatAdam, StepLR
+from .spec import Family, actor_shapes, critic_shapes, family_from_cfg
+from .vae import _default_init
+
+
+def _lstm_default_init(layout: Layout, gen: torch.Generator) -> Dict[str, torch.Tensor]:
+    """nn.Linear default for dense layers, nn.LSTM default U(-1/sqrt(H), 1/sqrt(H)) for LSTM tensors."""
+    out = _default_init(layout, gen)
+    for name, shp in layout.shapes.items():
+        if "lstm_layer." in name:
+            hid = shp[0] // 4
+            out[name] = (torch.rand(shp, generator=gen) * 2 - 1) / (hid ** 0.5)
+    return out
+
+
+# ------------------------------------------------------------------ networks
+class _ActorWork:
+    def __init__(self, net: "ActorNet", B: int, dev):
+        e = lambda *s: ops.dev_empty(*s, device=dev)
+        h0, h1 = net.h
+        self.xin = e(B, net.d_in) if net.needs_xin else None
+        self.h1, self.h2 = e(B, h0), e(B, h1)
+        self.d_h2, self.d_h1 = e(B, h1), e(B, h0)
+        self.d_xin = e(B, net.d_in) if net.lstm is not None else None
+        self.lstm_ws = net.lstm.workspace(B, dev) if net.lstm is not None else None
+
+
+class ActorNet:
+    """Actor (algorithm.py:159-180) / WorkerActor (:1187-1211)."""
+
+    def __init__(self, fam: Family, k: int, device, trainable: bool, lr: float = 0.0):
+        self.fam, self.k, self.dev = fam, k, device
+        self.stream = fam.streams[k]
+        self.layout = Layout(actor_shapes(fam, k))
+        self.params = FlatBuffer(self.layout, device)
+        self.opt = FlatAdam(self.params, lr) if trainable else None
+        g = self.opt.g if trainable else None
+        s = self.stream
+        self.lstm = BiLstm(self.params, g, "lstm.", s.o, s.T, s.s) if s.T > 1 else None
+        self.d_in = s.feat + fam.goal_dim
+        self.needs_xin = self.lstm is not None or fam.goal_dim > 0
+        self.h = tuple(fam.actor_hidden)
+        self.a = fam.a_dims[k]
+        self.l1 = Lin(self.params, g, "l1", ACT_RELU)
+        self.l2 = Lin(self.params, g, "l2", ACT_RELU)
+        self.l3 = Lin(self.params, g, "l3", ACT_TANH)          # max_action == 1
+        self._work: Dict[int, _ActorWork] = {}
+
+    def work(self, B: int) -> _ActorWork:
+        w = self._work.get(B)
+        if w is None:
+            w = self._work[B] = _ActorWork(self, B, self.dev)
+        return w
+
+    def forward(self, B: int, obs: int, ld_obs: int, goal: Optional[int], ld_goal: int, out: int, ld_out: int) -> None:
+        w = self.work(B)
+        s = self.stream
+        if self.needs_xin:
+            if self.lstm is not None:
+                self.lstm.fwd(obs, ld_obs, P(w.xin), self.d_in, w.lstm_ws, B)
+            else:
+                ops.copy2d(obs, ld_obs, P(w.xin), self.d_in, B, s.o)
+            if self.fam.goal_dim:
+                ops.copy2d(goal, ld_goal, P(w.xin, s.feat), self.d_in, B, self.fam.goal_dim)
+            x, ldx = P(w.xin), self.d_in
+        else:
+            x, ldx = obs, ld_obs
+        w.x, w.ldx = x, ldx
+        self.l1.fwd(x, ldx, P(w.h1), self.h[0], B)
+        self.l2.fwd(P(w.h1), self.h[0], P(w.h2), self.h[1], B)
+        self.l3.fwd(P(w.h2), self.h[1], out, ld_out, B)
+
+    def backward(self, B: int, out: int, ld_out: int, d_out: int, ld_dout: int) -> None:
+        """Gradients of the most recent forward(B, ...) into this actor's flat
+        gradient buffer (added; the caller zeroes it)."""
+        w = self.work(B)
+        self.l3.bwd(P(w.h2), self.h[1], out, ld_out, d_out, ld_dout, P(w.d_h2), self.h[1], B)
+        self.l2.bwd(P(w.h1), self.h[0], P(w.h2), self.h[1], P(w.d_h2), self.h[1], P(w.d_h1), self.h[0], B)
+        if self.lstm is not None:
+            self.l1.bwd(w.x, w.ldx, P(w.h1), self.h[0], P(w.d_h1), self.h[0], P(w.d_xin), self.d_in, B)
+            self.lstm.bwd(P(w.d_xin), self.d_in, w.lstm_ws, B)
+        else:
+            self.l1.bwd(w.x, w.ldx, P(w.h1), self.h[0], P(w.d_h1), self.h[0], None, 0, B)
+
+
+class _CriticWork:
+    def __init__(self, net: "CriticNet", B: int, dev):
+        e = lambda *s: ops.dev_empty(*s, device=dev)
+        h0, h1 = net.h
+        self.xu = e(B, net.D)
+        self.a1, self.a2, self.q1 = e(B, h0), e(B, h1), e(B, 1)
+        self.b1, self.b2, self.q2 = e(B, h0), e(B, h1), e(B, 1)
+        self.d_q1, self.d_q2 = e(B, 1), e(B, 1)
+        self.d_a2, self.d_a1 = e(B, h1), e(B, h0)
+        self.d_xu = e(B, net.D)
+        self.lstm_ws = [l.workspace(B, dev) if l is not None else None for l in net.lstms]
+
+
+class CriticNet:
+    """CriticSingle / CriticDouble / CriticTriple / ManagerCritic / WorkerCritic
+    (algorithm.py:188-232, 352-405, 614-676, 867-911, 1214-1258): per-stream
+    BiLSTM (when T > 1), concatenation with [goal and] the joint action, two
+    independent Q heads."""
+
+    def __init__(self, fam: Family, device, trainable: bool, lr: float = 0.0):
+        self.fam, self.dev = fam, device
+        self.layout = Layout(critic_shapes(fam))
+        self.params = FlatBuffer(self.layout, device)
+        self.opt = FlatAdam(self.params, lr) if trainable else None
+        g = self.opt.g if trainable else None
+        self.lstms = [BiLstm(self.params, g, pre, s.o, s.T, s.s) if s.T > 1 else None
+                      for s, pre in zip(fam.streams, fam.critic_lstm_prefixes())]
+        self.D = fam.critic_in
+        self.h = tuple(fam.critic_hidden)
+        self.feat_cols: List[int] = []
+        col = 0
+        for s in fam.streams:
+            self.feat_cols.append(col)
+            col += s.feat
+        self.goal_col = col
+        col += fam.goal_dim
+        self.act_col = col
+        self.act_cols = [col + sum(fam.a_dims[:k]) for k in range(len(fam.a_dims))]
+        L = lambda n, a: Lin(self.params, g, n, a)
+        self.l1, self.l2, self.l3 = L("l1", ACT_RELU), L("l2", ACT_RELU), L("l3", ACT_NONE)
+        self.l4, self.l5, self.l6 = L("l4", ACT_RELU), L("l5", ACT_RELU), L("l6", ACT_NONE)
+        self._work: Dict[int, _CriticWork] = {}
+
+    def work(self, B: int) -> _CriticWork:
+        w = self._work.get(B)
+        if w is None:
+            w = self._work[B] = _CriticWork(self, B, self.dev)
+        return w
+
+    def features(self, B: int, obs: Sequence[Tuple[int, int]], goal: Optional[int], ld_goal: int) -> None:
+        """State part of the head input: LSTM features or raw observations, then the goal."""
+        w = self.work(B)
+        for s, lstm, col, (o_ptr, o_ld), ws in zip(self.fam.streams, self.lstms, self.feat_cols, obs, w.lstm_ws):
+            if lstm is not None:
+                lstm.fwd(o_ptr, o_ld, P(w.xu, col), self.D, ws, B)
+            else:
+                ops.copy2d(o_ptr, o_ld, P(w.xu, col), self.D, B, s.o)
+        if self.fam.goal_dim:
+            ops.copy2d(goal, ld_goal, P(w.xu, self.goal_col), self.D, B, self.fam.goal_dim)
+
+    def set_actions(self, B: int, src: int, ld_src: int) -> None:
+        """Joint action block copied from `src` (replay rows keep a1|a2|a3 adjacent)."""
+        w = self.work(B)
+        ops.copy2d(src, ld_src, P(w.xu, self.act_col), self.D, B, self.fam.act_dim)
+
+    def heads(self, B: int, q1_only: bool = False) -> None:
+        w = self.work(B)
+        h0, h1 = self.h
+        self.l1.fwd(P(w.xu), self.D, P(w.a1), h0, B)
+        self.l2.fwd(P(w.a1), h0, P(w.a2), h1, B)
+        self.l3.fwd(P(w.a2), h1, P(w.q1), 1, B)
+        if q1_only:
+            return
+        self.l4.fwd(P(w.xu), self.D, P(w.b1), h0, B)
+        self.l5.fwd(P(w.b1), h0, P(w.b2), h1, B)
+        self.l6.fwd(P(w.b2), h1, P(w.q2), 1, B)
+
+    def backward(self, B: int, both_heads: bool, param_grads: bool) -> None:
+        """Back-propagates w.d_q1 (and w.d_q2) to w.d_xu; with param_grads also
+        into the critic's gradient buffer, including its LSTMs."""
+        w = self.work(B)
+        h0, h1 = self.h
+        has_lstm = any(l is not None for l in self.lstms)
+        need_dxu = (not param_grads) or has_lstm
+        self.l3.bwd(P(w.a2), h1, None, 0, P(w.d_q1), 1, P(w.d_a2), h1, B, param_grads=param_grads)
+        self.l2.bwd(P(w.a1), h0, P(w.a2), h1, P(w.d_a2), h1, P(w.d_a1), h0, B, param_grads=param_grads)
+        self.l1.bwd(P(w.xu), self.D, P(w.a1), h0, P(w.d_a1), h0, P(w.d_xu) if need_dxu else None, self.D, B,
+                    param_grads=param_grads)
+        if both_heads:
+            self.l6.bwd(P(w.b2), h1, None, 0, P(w.d_q2), 1, P(w.d_a2), h1, B, param_grads=param_grads)
+            self.l5.bwd(P(w.b1), h0, P(w.b2), h1, P(w.d_a2), h1, P(w.d_a1), h0, B, param_grads=param_grads)
+            self.l4.bwd(P(w.xu), self.D, P(w.b1), h0, P(w.d_a1), h0, P(w.d_xu) if need_dxu else None, self.D, B,
+                        dx_accumulate=1, param_grads=param_grads)
+        if param_grads:
+            for lstm, col, ws in zip(self.lstms, self.feat_cols, w.lstm_ws):
+                if lstm is not None:
+                    lstm.bwd(P(w.d_xu, col), self.D, ws, B)
+
+
+# ------------------------------------------------------------------ replay
+class DictReplay:
+    """ManagerTD3.ReplayBuffer (algorithm.py:916-951): fp32 arrays by field."""
+
+    def __init__(self, capacity: int, obs_dim: int, act_dim: int, seq_len: int, use_opc: bool):
+        self.capacity = capacity
+        self.buffer = {
+            "obs": np.zeros((capacity, obs_dim), dtype=np.float32),
+            "next_obs": np.zeros((capacity, obs_dim), dtype=np.float32),
+            "action": np.zeros((capacity, act_dim), dtype=np.float32),
+            "reward": np.zeros((capacity, 1), dtype=np.float32),
+            "worker_obs": np.zeros((capacity, seq_len, 8, 8), dtype=np.float32),
+            "worker_act": np.zeros((capacity, seq_len, 8, 1), dtype=np.float32),
+        }
+        self.pointer = 0
+        self.useOPC = use_opc
+
+    def store_transition(self, *args):
+        o, a, r, o_, wo, wa = args
+        i = self.pointer % self.capacity
+        self.buffer["obs"][i] = o
+        self.buffer["action"][i] = a
+        self.buffer["reward"][i] = r
+        self.buffer["next_obs"][i] = o_
+        if self.useOPC:
+            self.buffer["worker_obs"][i] = np.array(wo)
+            self.buffer["worker_act"][i] = np.array(wa)
+        self.pointer += 1
+
+    def __getitem__(self, item):
+        return self.buffer[item]
+
+
+# ------------------------------------------------------------------ learner
+class TD3Learner:
+    """The update rule shared by every variant: WorkerTD3.learn
+    (algorithm.py:1316-1366), TD3Single.learn (:283-328), ManagerTD3.learn
+    (:1109-1168), HATD3Double.learn (:479-542), HATD3Triple.learn (:768-838).
+    """
+
+    def __init__(self, fam: Family, device: Optional[str] = None, seed: Optional[int] = None, group=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("hhrl_vae_amd needs an AMD GPU (no CPU fallback)")
+        self._lib = _lib.load()
+        self.fam = fam
+        self.device = torch.device(device or "cuda")
+        dev = self.device
+        gen = torch.Generator().manual_seed(3407 if seed is None else seed)
+        self.actor_names = fam.actor_names()
+        self.actors = [ActorNet(fam, k, dev, True, fam.actor_lr) for k in range(len(fam.a_dims))]
+        self.actor_targets = [ActorNet(fam, k, dev, False) for k in range(len(fam.a_dims))]
+        for a, t in zip(self.actors, self.actor_targets):
+            a.params.load(_lstm_default_init(a.layout, gen))
+            t.params.copy_from(a.params)                                # algorithm.py:258
+        self.critic = CriticNet(fam, dev, True, fam.critic_lr)
+        self.critic_target = CriticNet(fam, dev, False)
+        self.critic.params.load(_lstm_default_init(self.critic.layout, gen))
+        self.critic_target.params.copy_from(self.critic.params)        # :265
+        self.actor_scheds = [StepLR(a.opt, fam.actor_sched) for a in self.actors]
+        self.critic_sched = StepLR(self.critic.opt, fam.critic_sched)
+        self.policy_freq = fam.policy_freq
+        self.total_it = 0
+        self.batch_size = fam.batch_size
+        self.gamma, self.tau = fam.gamma, fam.tau
+        self.memory_capacity = fam.memory_capacity
+        self.learn_begin = fam.memory_capacity * fam.learn_start_ratio
+        self.group = group
+        self.world_size = 1
+        if group is not None:
+            import torch.distributed as dist
+            self.world_size = dist.get_world_size(group)
+        self._rng = torch.Generator(device=dev)
+        self._rng.manual_seed(3407)
+        self._loss = ops.dev_zeros(2, device=dev)
+        self._pi: Dict[int, List[torch.Tensor]] = {}
+        self._y: Dict[int, torch.Tensor] = {}
+        # column offsets inside a replay row
+        f = fam
+        pos = 0
+        self.col_obs = []
+        for s in f.streams:
+            self.col_obs.append(pos); pos += s.width
+        self.col_act = pos; pos += f.act_dim
+        self.col_goal = pos; pos += f.goal_dim
+        self.col_next_goal = pos; pos += f.goal_dim
+        self.col_reward = pos; pos += 1
+        self.col_next_obs = []
+        for s in f.streams:
+            self.col_next_obs.append(pos); pos += s.width
+        assert pos == f.row_width
+        self.last_critic_loss: Optional[torch.Tensor] = None
+
+    # ---- batches ----------------------------------------------------------
+    def _sample_rows(self, indices: np.ndarray) -> np.ndarray:
+        raise NotImplementedError
+
+    def _n_stored(self) -> int:
+        raise NotImplementedError
+
+    def _upload(self, rows: np.ndarray) -> torch.Tensor:
+        t = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32))
+        return t.to(self.device, non_blocking=False)
+
+    # ---- the update -------------------------------------------------------
+    def learn_rows(self, rows: torch.Tensor, noise: Optional[Sequence] = None, order: Optional[Sequence[int]] = None) -> None:
+        """One TD3 update on a [B, row_width] fp32 device block of replay rows."""
+        fam, lib, st = self.fam, self._lib, _lib.stream_ptr()
+        B, W = int(rows.shape[0]), fam.row_width
+        if rows.dim() != 2 or rows.shape[1] != W or B == 0:
+            raise ValueError("rows must be [B, %d], got %s" % (W, tuple(rows.shape)))
+        rows = rows.contiguous()
+        n_act = len(self.actors)
+        if noise is None:
+            noise = [torch.randn((B, a), generator=self._rng, device=self.device, dtype=torch.float32) for a in fam.a_dims]
+        else:
+            noise = [torch.as_tensor(np.asarray(e) if not isinstance(e, torch.Tensor) else e, dtype=torch.float32)
+                     .to(self.device).contiguous() for e in noise]
+            for e, a in zip(noise, fam.a_dims):
+                if tuple(e.shape) != (B, a):
+                    raise ValueError("noise must be [%d, %d], got %s" % (B, a, tuple(e.shape)))
+        self.total_it += 1
+        inv_n = 1.0 / float(B * self.world_size)
+        R = lambda col: P(rows, col)
+        goal = R(self.col_goal) if fam.goal_dim else None
+        next_goal = R(self.col_next_goal) if fam.goal_dim else None
+        obs = [(R(c), W) for c in self.col_obs]
+        next_obs = [(R(c), W) for c in self.col_next_obs]
+        if B not in self._pi:
+            self._pi[B] = [ops.dev_empty(B, a, device=self.device) for a in fam.a_dims]
+            self._y[B] = ops.dev_empty(B, 1, device=self.device)
+        pi, y = self._pi[B], self._y[B]
+
+        # -- target value (no gradient): algorithm.py:1329-1337 / 785-796
+        ct, cw_t = self.critic_target, self.critic_target.work(B)
+        for k, (at, eps) in enumerate(zip(self.actor_targets, noise)):
+            at.forward(B, next_obs[k][0], W, next_goal, W, P(pi[k]), fam.a_dims[k])
+            check(lib.hhrl_td3_smooth_action(P(pi[k]), fam.a_dims[k], P(eps), P(cw_t.xu, ct.act_cols[k]), ct.D, B,
+                                             fam.a_dims[k], st))
+        ct.features(B, next_obs, next_goal, W)
+        ct.heads(B)
+        check(lib.hhrl_td3_target_q(P(cw_t.q1), P(cw_t.q2), R(self.col_reward), W, fam.gamma, P(y), B, st))
+
+        # -- critic step: :1341-1350 / 799-808
+        c, cw = self.critic, self.critic.work(B)
+        c.opt.zero_grad()
+        self._loss.zero_()
+        c.features(B, obs, goal, W)
+        c.set_actions(B, R(self.col_act), W)
+        c.heads(B)
+        check(lib.hhrl_twin_mse(P(cw.q1), P(cw.q2), P(y), inv_n, P(self._loss), P(cw.d_q1), P(cw.d_q2), B, st))
+        c.backward(B, both_heads=True, param_grads=True)
+        self._allreduce(c.opt.g)
+        c.opt.step()
+        self.critic_sched.step()
+
+        # -- delayed policy step: :1353-1366 / 811-838
+        if self.total_it % self.policy_freq == 0:
+            if order is None:
+                order = np.random.permutation(n_act) if n_act > 1 else [0]
+            order = [int(i) for i in order]
+            if sorted(order) != list(range(n_act)):
+                raise ValueError("order must be a permutation of range(%d)" % n_act)
+            if any(l is not None for l in c.lstms):
+                c.features(B, obs, goal, W)           # LSTM features under the updated critic weights
+            for j, a in enumerate(self.actors):       # joint action written straight into the critic input
+                a.forward(B, obs[j][0], W, goal, W, P(cw.xu, c.act_cols[j]), c.D)
+            for n, i in enumerate(order):
+                a = self.actors[i]
+                c.heads(B, q1_only=True)
+                ops.fill(P(cw.d_q1), B, -inv_n)       # d(-mean Q1)/dQ1
+                c.backward(B, both_heads=False, param_grads=False)
+                a.opt.zero_grad()
+                a.backward(B, P(cw.xu, c.act_cols[i]), c.D, P(cw.d_xu, c.act_cols[i]), c.D)
+                self._allreduce(a.opt.g)
+                a.opt.step()
+                if n + 1 < len(order):                # later actors see this actor's new policy
+                    a.forward(B, obs[i][0], W, goal, W, P(cw.xu, c.act_cols[i]), c.D)
+            ops.polyak(self.critic_target.params, self.critic.params, fam.tau)
+            for a, t in zip(self.actors, self.actor_targets):
+                ops.polyak(t.params, a.params, fam.tau)
+            for s in self.actor_scheds:
+                s.step()
+        self._keep = (rows, noise)
+        self.last_critic_loss = self._loss
+
+    def _allreduce(self, g: FlatBuffer) -> None:
+        if self.group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(g.data, group=self.group)
+
+    def _learn(self, indices=None, noise=None, order=None) -> None:
+        if indices is None:
+            indices = np.random.choice(min(self._n_stored(), self.memory_capacity), size=self.batch_size)
+        rows = self._upload(self._sample_rows(np.asarray(indices)))
+        self.learn_rows(rows, noise, order)
+
+    # ---- inference --------------------------------------------------------
+    def _act(self, k: int, obs, goal=None) -> np.ndarray:
+        """Batch-1 policy evaluation (choose_* methods, algorithm.py:279-281 ...)."""
+        s = self.fam.streams[k]
+        o = torch.as_tensor(np.asarray(obs, dtype=np.float32)).reshape(1, -1)
+        if o.shape[1] != s.width:
+            raise ValueError("expected %d observation values, got %d" % (s.width, o.shape[1]))
+        return self._policy_batch(k, o, goal)[0]
+
+    def _policy_batch(self, k: int, obs, goal=None) -> np.ndarray:
+        s = self.fam.streams[k]
+        o = torch.as_tensor(np.asarray(obs, dtype=np.float32)).reshape(-1, s.width).to(self.device).contiguous()
+        n = int(o.shape[0])
+        g_ptr, g_t = None, None
+        if self.fam.goal_dim:
+            g_t = torch.as_tensor(np.asarray(goal, dtype=np.float32)).reshape(n, self.fam.goal_dim).to(self.device).contiguous()
+            g_ptr = P(g_t)
+        out = ops.dev_empty(n, self.fam.a_dims[k], device=self.device)
+        self.actors[k].forward(n, P(o), s.width, g_ptr, self.fam.goal_dim, P(out), self.fam.a_dims[k])
+        return out.cpu().numpy()
+
+    # ---- checkpoints ------------------------------------------------------
+    def state_dicts(self) -> Dict[str, Dict[str, torch.Tensor]]:
+        d = {n: a.params.state_dict() for n, a in zip(self.actor_names, self.actors)}
+        d["critic"] = self.critic.params.state_dict()
+        return d
+
+    def target_state_dicts(self) -> Dict[str, Dict[str, torch.Tensor]]:
+        d = {n: a.params.state_dict() for n, a in zip(self.actor_names, self.actor_targets)}
+        d["critic"] = self.critic_target.params.state_dict()
+        return d
+
+    def load_state_dicts(self, sds: Dict[str, dict]) -> None:
+        """Loads networks and re-creates the targets as copies, like `load`
+        does with deepcopy (algorithm.py:337-344)."""
+        for n, a, t in zip(self.actor_names, self.actors, self.actor_targets):
+            if n in sds:
+                a.params.load(sds[n])
+                t.params.copy_from(a.params)
+        if "critic" in sds:
+            self.critic.params.load(sds["critic"])
+            self.critic_target.params.copy_from(self.critic.params)
+
+    def _nets(self):
+        return list(zip(self.actor_names, self.actors)) + [("critic", self.critic)]
+
+    def save(self, filename: str) -> None:
+        """`<prefix>_actor[k]`, `_actor[k]_optimizer`, `_critic`, `_critic_optimizer`
+        (algorithm.py:330-335, 544-551, 840-849, 1170-1175, 1368-1373)."""
+        for n, net in self._nets():
+            torch.save(net.params.state_dict(), filename + "_" + n)
+            torch.save(net.opt.state_dict(), filename + "_" + n + "_optimizer")
+
+    def load(self, filename: str) -> None:
+        sds = {}
+        for n, net in self._nets():
+            sds[n] = torch.load(filename + "_" + n, weights_only=True)
+            net.opt.load_state_dict(torch.load(filename + "_" + n + "_optimizer", weights_only=True))
+        self.load_state_dicts(sds)
+
+
+class _FlatReplayMixin:
+    """`np.zeros((capacity, row))` float64 ring buffer with np.hstack rows
+    (algorithm.py:252, 273-277)."""
+
+    def _init_memory(self):
+        self.memory = np.zeros((self.memory_capacity, self.fam.row_width))
+        self.pointer = 0
+
+    def _store(self, *parts) -> None:
+        transition = np.hstack(parts)
+        self.memory[self.pointer % self.memory_capacity, :] = transition
+        self.pointer += 1
+
+    def _sample_rows(self, indices):
+        return self.memory[indices, :]
+
+    def _n_stored(self):
+        return self.pointer
+
+
+# ------------------------------------------------------------------ reference surface
+class TD3Single(_FlatReplayMixin, TD3Learner):
+    """algorithm.py:235-344."""
+
+    def __init__(self, cfg: dict, task: str, **kw):
+        super().__init__(family_from_cfg("single", cfg, task), **kw)
+        s = self.fam.streams[0]
+        self.o_dim, self.a_dim, self.s_dim, self.t = s.o, self.fam.a_dims[0], s.s, s.T
+        self.obs_dim = s.width
+        self.a1_dim = self.a2_dim = self.a3_dim = self.a_dim
+        self.choose_time_action = self.choose_phase_action = self.choose_goal = self.choose_action
+        self._init_memory()
+
+    def store_transition(self, o, a, r, o_):
+        self._store(o, a, r, o_)
+
+    def choose_action(self, o):
+        return self._act(0, o).flatten()
+
+    def learn(self, indices=None, noise=None, order=None):
+        self._learn(indices, noise, order)
+
+
+class HATD3Double(_FlatReplayMixin, TD3Learner):
+    """algorithm.py:409-563 (time|phase + vehicle)."""
+
+    _kind = "double"
+
+    def __init__(self, cfg: dict, light_opt: Optional[str] = None, **kw):
+        super().__init__(family_from_cfg(self._kind, cfg, light_opt), **kw)
+        self.use_opc = cfg["use_opc"]
+        s1, s2 = self.fam.streams
+        self.o1_dim, self.s1_dim, self.a1_dim, self.t1 = s1.o, s1.s, self.fam.a_dims[0], s1.T
+        self.o2_dim, self.s2_dim, self.a2_dim, self.t2 = s2.o, s2.s, self.fam.a_dims[1], s2.T
+        self.obs1_dim, self.obs2_dim = s1.width, s2.width
+        self.obs_dim, self.act_dim = self.fam.obs_dim, self.fam.act_dim
+        self.choose_time_action = self.choose_phase_action = self.choose_light_action
+        self._init_memory()
+
+    def store_transition(self, o1, o2, a1, a2, r, o1_, o2_):
+        self._store(o1, o2, a1, a2, r, o1_, o2_)
+
+    def choose_light_action(self, o1):
+        return self._act(0, o1).flatten()
+
+    def choose_goal(self, o2):
+        return self._act(1, o2).flatten()
+
+    def learn(self, worker_policy=None, indices=None, noise=None, order=None):
+        self._learn(indices, noise, order)
+
+
+class HATD3(HATD3Double):
+    """algorithm.py:567-606 (time + phase)."""
+
+    _kind = "tp"
+
+    def __init__(self, cfg: dict, **kw):
+        super().__init__(cfg, None, **kw)
+        self.choose_time_action = self.choose_light_action
+        self.choose_phase_action = self.choose_goal
+
+
+class HATD3Triple(_FlatReplayMixin, TD3Learner):
+    """algorithm.py:679-864 (time + phase + vehicle)."""
+
+    def __init__(self, cfg: dict, **kw):
+        super().__init__(family_from_cfg("triple", cfg), **kw)
+        self.use_opc = cfg["use_opc"]
+        for i, s in enumerate(self.fam.streams, 1):
+            setattr(self, "o%d_dim" % i, s.o)
+            setattr(self, "s%d_dim" % i, s.s)
+            setattr(self, "a%d_dim" % i, self.fam.a_dims[i - 1])
+            setattr(self, "t%d" % i, s.T)
+            setattr(self, "obs%d_dim" % i, s.width)
+        self.obs_dim, self.act_dim = self.fam.obs_dim, self.fam.act_dim
+        self._init_memory()
+
+    def store_transition(self, o1, o2, o3, a1, a2, a3, r, o1_, o2_, o3_):
+        self._store(o1, o2, o3, a1, a2, a3, r, o1_, o2_, o3_)
+
+    def choose_time_action(self, o1):
+        return self._act(0, o1).flatten()
+
+    def choose_phase_action(self, o2):
+        return self._act(1, o2).flatten()
+
+    def choose_goal(self, o3):
+        return self._act(2, o3).flatten()
+
+    def learn(self, worker_policy=None, indices=None, noise=None, order=None):
+        self._learn(indices, noise, order)
+
+
+class ManagerTD3(TD3Learner):
+    """algorithm.py:915-1184 (goal-only manager).  Off-policy correction
+    (`use_opc`, :1007-1107) is disabled in the reference's configuration
+    (configs.py:73) and is not provided here."""
+
+    def __init__(self, cfg: dict, **kw):
+        if cfg["use_opc"]:
+            raise NotImplementedError("off-policy correction (use_opc=True) is outside the accelerated path")
+        super().__init__(family_from_cfg("manager", cfg), **kw)
+        self.use_opc = False
+        s = self.fam.streams[0]
+        self.o_dim, self.a_dim, self.s_dim, self.t = s.o, self.fam.a_dims[0], s.s, s.T
+        self.obs_dim = s.width
+        self.choose_goal = self.choose_action
+        self.memory = DictReplay(self.memory_capacity, self.obs_dim, self.a_dim, 25, self.use_opc)
+        self.store_transition = self.memory.store_transition
+
+    @property
+    def pointer(self):
+        return self.memory.pointer
+
+    def _n_stored(self):
+        return self.memory.pointer
+
+    def _sample_rows(self, indices):
+        m = self.memory
+        return np.hstack((m["obs"][indices], m["action"][indices], m["reward"][indices], m["next_obs"][indices]))
+
+    def choose_action(self, o_l):
+        return self._act(0, o_l).flatten()
+
+    def learn(self, worker_policy=None, indices=None, noise=None, order=None):
+        self._learn(indices, noise, order)
+
+
+class WorkerTD3(_FlatReplayMixin, TD3Learner):
+    """algorithm.py:1261-1382 (goal-conditioned CAV agent)."""
+
+    def __init__(self, cfg: dict, **kw):
+        super().__init__(family_from_cfg("worker", cfg), **kw)
+        s = self.fam.streams[0]
+        self.o_dim, self.a_dim, self.s_dim, self.t = s.o, self.fam.a_dims[0], s.s, s.T
+        self.g_dim = self.fam.goal_dim
+        self.obs_dim = s.width
+        self._init_memory()
+
+    def store_transition(self, o, a, g, g_, r, o_):
+        self._store(o, a, g, g_, r, o_)
+
+    def choose_action(self, o, g):
+        return self._act(0, o, g).flatten()
+
+    def policy(self, o, g):
+        """Batched policy for the manager's off-policy correction (algorithm.py:1310-1314)."""
+        return self._policy_batch(0, o, g)
+
+    def learn(self, indices=None, noise=None, order=None):
+        self._learn(indices, noise, order)

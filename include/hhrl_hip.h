@@ -98,8 +98,9 @@ int hhrl_vae_latent_grad(const float* dz, const float* ml, const float* eps, flo
  *   out = clamp(pi + clamp(0.2*eps, -0.5, 0.5), -1, 1);  eps ~ N(0,1) from the caller. */
 int hhrl_td3_smooth_action(const float* pi, int ldp, const float* eps, float* out, int ldo,
                            int B, int a, void* stream);
-/* y = r + gamma*min(q1,q2)                  (algorithm.py:300-301, 502-503, 795-796, 1140-1141, 1336-1337) */
-int hhrl_td3_target_q(const float* q1, const float* q2, const float* r, float gamma, float* y,
+/* y = r + gamma*min(q1,q2)                  (algorithm.py:300-301, 502-503, 795-796, 1140-1141, 1336-1337)
+ * r is a column of the sampled replay rows: element b at r[b*ldr]. */
+int hhrl_td3_target_q(const float* q1, const float* q2, const float* r, int ldr, float gamma, float* y,
                       int B, void* stream);
 /* Twin critic loss and its gradient (F.mse_loss x2, algorithm.py:307, 509, 802, 1147, 1344):
  *   loss[0] += inv_n*sum((q1-y)^2); loss[1] += inv_n*sum((q2-y)^2);
@@ -134,11 +135,13 @@ int hhrl_lstm_backward(const float* const* params, const float* d_out, int lddo,
  * (algorithm.py:83, 106, 259, 266, 312, 320 ...): bias-corrected, no weight
  * decay, no amsgrad.  `step` is the 1-based step count AFTER this update;
  * lr comes from the host-side StepLR rule.  g is multiplied by grad_scale
- * first (1.0 normally; 1/world for an averaged all-reduce). */
-int hhrl_adam_step(float* p, const float* g, float* m, float* v, long n, float lr,
-                   float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+ * first (1.0 normally; 1/world for an averaged all-reduce).  Hyper-parameters
+ * are doubles: 1-beta and the bias corrections are formed in double on the
+ * host, as torch forms them, and only then rounded to fp32 kernel scalars. */
+int hhrl_adam_step(float* p, const float* g, float* m, float* v, long n, double lr,
+                   double beta1, double beta2, double eps, int step, double grad_scale, void* stream);
 /* target = tau*p + (1-tau)*target          (algorithm.py:323-326, 534-539, 827-834, 1163-1166, 1361-1364) */
-int hhrl_polyak_update(float* target, const float* p, long n, float tau, void* stream);
+int hhrl_polyak_update(float* target, const float* p, long n, double tau, void* stream);
 
 #ifdef __cplusplus
 }

@@ -107,7 +107,8 @@ def test_adam_and_polyak(env, n):
         gr = torch.randn(n, generator=g) * 10.0 ** (-step)
         ref_p.grad = gr.clone()
         opt.step()
-        L.check(lib.hhrl_adam_step(pd.data_ptr(), gr.to(dev).data_ptr(), md.data_ptr(), vd.data_ptr(), n, 1e-3, 0.9, 0.999,
+        grd = gr.to(dev)
+        L.check(lib.hhrl_adam_step(pd.data_ptr(), grd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, 1e-3, 0.9, 0.999,
                                    1e-8, step, 1.0, L.stream_ptr()))
         scaled_close("p%d" % step, pd.cpu().numpy(), ref_p.detach().numpy(), rtol=1e-5, atol_rel=1e-7)
     st = opt.state[ref_p]
@@ -143,7 +144,8 @@ def test_data_movement(env):
     scaled_close("sum_pool", out[:, :Cc].cpu().numpy(), x[:, :Cc].view(B, N, Cc).sum(1).numpy())
     src = torch.randn(B, Cc, generator=g)
     dst = torch.zeros(B * N, ld, device=dev)
-    L.check(lib.hhrl_broadcast_rows(src.to(dev).data_ptr(), Cc, dst.data_ptr() + 4 * 8, ld, B, N, Cc, L.stream_ptr()))
+    srcd = src.to(dev)
+    L.check(lib.hhrl_broadcast_rows(srcd.data_ptr(), Cc, dst.data_ptr() + 4 * 8, ld, B, N, Cc, L.stream_ptr()))
     assert torch.equal(dst[:, 8:8 + Cc].cpu(), src.repeat_interleave(N, 0))
     assert torch.all(dst[:, :8] == 0)
     c = torch.zeros(B * N, 12, device=dev)
@@ -174,12 +176,14 @@ def test_vae_elementwise(env):
     (recon + kl + (z * dz).sum()).backward()
     loss = torch.zeros(1, device=dev)
     ddec = torch.zeros(B * N, 1, device=dev)
-    L.check(lib.hhrl_vae_elbo(dec.detach().to(dev).data_ptr(), data.to(dev).data_ptr(), mld.data_ptr(), 1.0 / (B * N),
+    decd, datad = dec.detach().to(dev), data.to(dev)          # keep device operands referenced while kernels run
+    L.check(lib.hhrl_vae_elbo(decd.data_ptr(), datad.data_ptr(), mld.data_ptr(), 1.0 / (B * N),
                               loss.data_ptr(), ddec.data_ptr(), B, N, gd, st))
     scaled_close("loss", loss.cpu().numpy(), [float(recon + kl)])
     scaled_close("ddec", ddec.cpu().numpy(), dec.grad.numpy())
     dml = torch.zeros(B, 2 * gd, device=dev)
-    L.check(lib.hhrl_vae_latent_grad(dz.to(dev).data_ptr(), mld.data_ptr(), epsd.data_ptr(), dml.data_ptr(), B, gd, st))
+    dzd = dz.to(dev)
+    L.check(lib.hhrl_vae_latent_grad(dzd.data_ptr(), mld.data_ptr(), epsd.data_ptr(), dml.data_ptr(), B, gd, st))
     scaled_close("dml", dml.cpu().numpy(), ml.grad.numpy())
 
 
@@ -191,7 +195,8 @@ def test_td3_elementwise(env):
     eps = torch.randn(B, a, generator=g) * 3
     out = torch.zeros(B, a + 5, device=dev)
     st = L.stream_ptr()
-    L.check(lib.hhrl_td3_smooth_action(pi.to(dev).data_ptr(), a + 2, eps.to(dev).data_ptr(), out.data_ptr() + 4 * 5, a + 5, B, a, st))
+    pid, epsd = pi.to(dev), eps.to(dev)
+    L.check(lib.hhrl_td3_smooth_action(pid.data_ptr(), a + 2, epsd.data_ptr(), out.data_ptr() + 4 * 5, a + 5, B, a, st))
     want = (pi[:, :a] + (eps * 0.2).clamp(-0.5, 0.5)).clamp(-1, 1)
     scaled_close("smooth", out[:, 5:].cpu().numpy(), want.numpy(), rtol=1e-6)
     q1 = torch.randn(B, 1, generator=g).requires_grad_(True)
@@ -200,13 +205,15 @@ def test_td3_elementwise(env):
     tq1, tq2 = torch.randn(B, 1, generator=g), torch.randn(B, 1, generator=g)
     y = r + 0.95 * torch.min(tq1, tq2)
     yd = torch.zeros(B, 1, device=dev)
-    L.check(lib.hhrl_td3_target_q(tq1.to(dev).data_ptr(), tq2.to(dev).data_ptr(), r.to(dev).data_ptr(), 0.95, yd.data_ptr(), B, st))
+    tq1d, tq2d, rd = tq1.to(dev), tq2.to(dev), r.to(dev)
+    L.check(lib.hhrl_td3_target_q(tq1d.data_ptr(), tq2d.data_ptr(), rd.data_ptr(), 1, 0.95, yd.data_ptr(), B, st))
     scaled_close("y", yd.cpu().numpy(), y.numpy(), rtol=1e-6)
     l1, l2 = F.mse_loss(q1, y), F.mse_loss(q2, y)
     (l1 + l2).backward()
     loss = torch.zeros(2, device=dev)
     dq1, dq2 = torch.zeros(B, 1, device=dev), torch.zeros(B, 1, device=dev)
-    L.check(lib.hhrl_twin_mse(q1.detach().to(dev).data_ptr(), q2.detach().to(dev).data_ptr(), yd.data_ptr(), 1.0 / B,
+    q1d, q2d = q1.detach().to(dev), q2.detach().to(dev)
+    L.check(lib.hhrl_twin_mse(q1d.data_ptr(), q2d.data_ptr(), yd.data_ptr(), 1.0 / B,
                               loss.data_ptr(), dq1.data_ptr(), dq2.data_ptr(), B, st))
     scaled_close("mse", loss.cpu().numpy(), [float(l1), float(l2)])
     scaled_close("dq1", dq1.cpu().numpy(), q1.grad.numpy())
@@ -236,9 +243,10 @@ def test_lstm_forward_backward(env, B, T, o, H):
     ws = torch.empty(lib.hhrl_lstm_workspace_floats(B, T, o, H), device=dev)
     od = torch.zeros(B, H + 2, device=dev)
     st = L.stream_ptr()
-    L.check(lib.hhrl_lstm_forward(obs.to(dev).data_ptr(), ld, parr, od.data_ptr(), H + 2, ws.data_ptr(), B, T, o, H, st))
+    obsd, doutd = obs.to(dev), dout.to(dev)
+    L.check(lib.hhrl_lstm_forward(obsd.data_ptr(), ld, parr, od.data_ptr(), H + 2, ws.data_ptr(), B, T, o, H, st))
     scaled_close("out", od[:, :H].cpu().numpy(), out.detach().numpy(), atol_rel=5e-6)
-    L.check(lib.hhrl_lstm_backward(parr, dout.to(dev).data_ptr(), H + 2, garr, ws.data_ptr(), B, T, o, H, st))
+    L.check(lib.hhrl_lstm_backward(parr, doutd.data_ptr(), H + 2, garr, ws.data_ptr(), B, T, o, H, st))
     for n, p, gdev in zip(names + ["fc.weight", "fc.bias"], ps, gd):
         want = p.grad if p.grad is not None else torch.zeros_like(p)
         scaled_close("grad " + n, gdev.cpu().numpy(), want.numpy(), atol_rel=1e-5)

@@ -1,0 +1,167 @@
+"""TD3 family updates on the GPU (through the C ABI) replayed against the
+golden vectors recorded from the reference: same initial weights, replay rows,
+sampled indices, smoothing noise and actor order.  Bar: fp32, rtol 1e-4 (plus
+an absolute floor tied to each tensor's scale, see test_gpu_kernels)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gen
+import hhrl_oracle as O
+from golden_util import assert_close, load_case, sub, td3_inputs
+from test_gpu_kernels import scaled_close
+
+pytestmark = pytest.mark.gpu
+
+
+def build(kind, task, cfg):
+    import hhrl_vae_amd.algorithm as A
+    if kind == "single":
+        return A.TD3Single(cfg, task)
+    if kind == "double":
+        return A.HATD3Double(cfg, task)
+    if kind == "tp":
+        return A.HATD3(cfg)
+    if kind == "triple":
+        return A.HATD3Triple(cfg)
+    if kind == "manager":
+        return A.ManagerTD3(cfg)
+    return A.WorkerTD3(cfg)
+
+
+def fill_memory(net, kind, rows):
+    n = rows.shape[0]
+    if kind == "manager":
+        od, ad = net.obs_dim, net.a_dim
+        b = net.memory.buffer
+        b["obs"][:n], b["action"][:n] = rows[:, :od], rows[:, od: od + ad]
+        b["reward"][:n], b["next_obs"][:n] = rows[:, od + ad: od + ad + 1], rows[:, od + ad + 1:]
+        net.memory.pointer = n
+    else:
+        net.memory[:n] = rows
+        net.pointer = n
+
+
+def close_dict(name, got, want, digest, atol_rel=2e-6):
+    assert set(want) <= set(got), (name, sorted(set(want) - set(got)))
+    for k, w in want.items():
+        g = got[k].numpy() if isinstance(got[k], torch.Tensor) else np.asarray(got[k])
+        if not digest:
+            scaled_close(name + "/" + k, g, w, atol_rel=atol_rel)
+            continue
+        d = gen.digest(g)
+        mean_abs = w[1] / max(g.size, 1)
+        assert_close(name + "/" + k + "[sum]", d[0], w[0], rtol=1e-4, atol=atol_rel * 10 * max(w[1], 1e-30))
+        assert_close(name + "/" + k + "[abs]", d[1], w[1], rtol=1e-4, atol=0)
+        assert_close(name + "/" + k + "[samples]", d[2:], w[2:], rtol=1e-4, atol=atol_rel * 20 * max(mean_abs, 1e-30))
+
+
+@pytest.mark.parametrize("case", list(gen.TD3_CASES))
+def test_td3_golden(case):
+    kind, task, mkcfg, n_rows, n_calls, mode = gen.TD3_CASES[case]
+    fx = load_case("td3_" + case)
+    cfg = mkcfg()
+    net = build(kind, task, cfg)
+    fam = net.fam
+    names = net.actor_names
+    ofam = O.family_from_cfg(kind, mkcfg(), task)
+    shapes = {n: O.actor_param_shapes(ofam, k) for k, n in enumerate(names)}
+    shapes["critic"] = O.critic_param_shapes(ofam)
+    init, rows = td3_inputs(case, fx, shapes)
+    assert rows.shape[1] == fam.row_width == int(fx["row_width"])
+    net.load_state_dicts(init)
+    fill_memory(net, kind, rows)
+    dg = mode == "digest"
+    for call in range(n_calls):
+        pre = "call%d" % call
+        noise = [fx[pre + "/eps%d" % j] for j in range(len(names))]
+        net.learn(indices=fx[pre + "/indices"], noise=noise, order=fx[pre + "/order"])
+        scaled_close(pre + "/mse", net.last_critic_loss.cpu().numpy(), fx[pre + "/mse"])
+        close_dict(pre + "/grad/critic", net.critic.opt.g.state_dict(), sub(fx, pre + "/grad/critic"), dg, atol_rel=5e-6)
+        close_dict(pre + "/param/critic", net.critic.params.state_dict(), sub(fx, pre + "/param/critic"), dg)
+        if bool(fx[pre + "/policy"]):
+            for k, n in enumerate(names):
+                close_dict(pre + "/grad/" + n, net.actors[k].opt.g.state_dict(), sub(fx, pre + "/grad/" + n), dg, atol_rel=5e-6)
+                close_dict(pre + "/param/" + n, net.actors[k].params.state_dict(), sub(fx, pre + "/param/" + n), dg)
+                close_dict(pre + "/target/" + n, net.actor_targets[k].params.state_dict(), sub(fx, pre + "/target/" + n), dg)
+            close_dict(pre + "/target/critic", net.critic_target.params.state_dict(), sub(fx, pre + "/target/critic"), dg)
+        assert_close(pre + "/lr_critic", net.critic.opt.lr, fx[pre + "/lr_critic"], rtol=1e-12, atol=0)
+        assert_close(pre + "/lr_actor", net.actors[0].opt.lr, fx[pre + "/lr_actor"], rtol=1e-12, atol=0)
+    for k, n in enumerate(names + ["critic"]):
+        opt = net.critic.opt if n == "critic" else net.actors[k].opt
+        close_dict("exp_avg/" + n, opt.m.state_dict(), sub(fx, "final/exp_avg/" + n), dg, atol_rel=5e-6)
+        close_dict("exp_avg_sq/" + n, opt.v.state_dict(), sub(fx, "final/exp_avg_sq/" + n), dg, atol_rel=1e-5)
+    if not dg:
+        fns = {"single": ["choose_action"], "manager": ["choose_action"], "worker": ["choose_action"],
+               "double": ["choose_light_action", "choose_goal"], "tp": ["choose_time_action", "choose_phase_action"],
+               "triple": ["choose_time_action", "choose_phase_action", "choose_goal"]}[kind]
+        for k, n in enumerate(names):
+            args = [fx["choose/%s/o" % n]] + ([fx["choose/%s/g" % n]] if kind == "worker" else [])
+            out = getattr(net, fns[k])(*args)
+            assert out.ndim == 1
+            scaled_close("choose/" + n, out, fx["choose/%s/out" % n], atol_rel=5e-6)
+        if "policy/out" in fx:
+            scaled_close("policy", net.policy(fx["policy/o"], fx["policy/g"]), fx["policy/out"], atol_rel=5e-6)
+
+
+def test_td3_store_and_sample_surface():
+    """store_transition layouts, pointer / learn_begin bookkeeping and an
+    un-injected learn() (own indices, noise and order) run end to end."""
+    import hhrl_vae_amd.algorithm as A
+    cfg = gen.cav_cfg(o=5, g=3, hidden=(16, 12), batch=8, cap=20)
+    w = A.WorkerTD3(cfg)
+    assert w.memory.shape == (20, 2 * (5 + 3) + 1 + 1) and w.learn_begin == 20 * 0.4
+    rs = np.random.RandomState(0)
+    for i in range(25):                                    # wraps around the ring
+        w.store_transition(rs.rand(5), rs.rand(1), rs.rand(3), rs.rand(3), [0.5], rs.rand(5))
+    assert w.pointer == 25 and np.all(w.memory[:, 12] == 0.5)
+    before = w.state_dicts()["critic"]["l1.weight"].clone()
+    w.learn(); w.learn()
+    assert w.total_it == 2 and not torch.equal(before, w.state_dicts()["critic"]["l1.weight"])
+    t = A.HATD3Triple(gen.light_cfg(o=(5, 6, 7), T=4, s=8, a=(1, 2, 3), actor_h=(12, 10), critic_h=(14, 12), batch=8, cap=16))
+    assert t.memory.shape[1] == 2 * 4 * (5 + 6 + 7) + 6 + 1 and (t.a1_dim, t.a2_dim, t.a3_dim, t.t1) == (1, 2, 3, 4)
+    for i in range(10):
+        t.store_transition(rs.rand(20), rs.rand(24), rs.rand(28), rs.rand(1), rs.rand(2), rs.rand(3), 1.0,
+                           rs.rand(20), rs.rand(24), rs.rand(28))
+    t.learn(None); t.learn(None)
+    m = A.ManagerTD3(gen.light_cfg(o=(5, 5, 7), T=4, s=8, a=(1, 2, 3), veh_h=(12, 10), batch=8, cap=16))
+    for i in range(10):
+        m.store_transition(rs.rand(28), rs.rand(3), 0.25, rs.rand(28), None, None)
+    assert m.pointer == 10 and m.memory["reward"][3, 0] == 0.25
+    m.learn(None); m.learn(None)
+    with pytest.raises(NotImplementedError):
+        A.ManagerTD3(dict(gen.light_cfg(), use_opc=True))
+
+
+def test_td3_checkpoint_roundtrip(tmp_path):
+    """save/load: the reference's file suffixes and torch formats
+    (algorithm.py:1368-1382); a torch Adam accepts the optimizer file."""
+    import hhrl_vae_amd.algorithm as A
+    cfg = gen.cav_cfg(o=5, g=3, hidden=(16, 12), batch=8, cap=48)
+    w = A.WorkerTD3(cfg)
+    rows = gen.gen_rows(40, w.fam.row_width, 1)
+    w.memory[:40] = rows
+    w.pointer = 40
+    w.learn(); w.learn()
+    prefix = os.path.join(str(tmp_path), "cav_agent_x_ep_9")
+    w.save(prefix)
+    for suf in ("_actor", "_actor_optimizer", "_critic", "_critic_optimizer"):
+        assert os.path.exists(prefix + suf)
+    sd = torch.load(prefix + "_critic", weights_only=True)
+    assert list(sd) == ["l1.weight", "l1.bias", "l2.weight", "l2.bias", "l3.weight", "l3.bias",
+                        "l4.weight", "l4.bias", "l5.weight", "l5.bias", "l6.weight", "l6.bias"]
+    ps = [torch.nn.Parameter(v.clone()) for v in sd.values()]
+    topt = torch.optim.Adam(ps, lr=1e-3)
+    topt.load_state_dict(torch.load(prefix + "_critic_optimizer", weights_only=True))
+    assert float(topt.state[ps[0]]["step"]) == 2.0
+    w2 = A.WorkerTD3(gen.cav_cfg(o=5, g=3, hidden=(16, 12), batch=8, cap=48))
+    w2.load(prefix)
+    a, b = w.state_dicts(), w2.state_dicts()
+    for n in a:
+        for k in a[n]:
+            assert torch.equal(a[n][k], b[n][k])
+    tgt = w2.target_state_dicts()
+    assert all(torch.equal(tgt["actor"][k], b["actor"][k]) for k in b["actor"])      # targets re-created as copies
+    assert w2.critic.opt.step_count == 2 and w2.actors[0].opt.step_count == 1
