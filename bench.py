@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Headline benchmark: VAE training lane-samples/s (and agent-update
+minibatches/s as extra fields) on N MI355X of one node.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one `Encoder.learn` on one resident batch (forward, ELBO,
+backward, Adam) per GPU.  N=1 workload: 4096 lanes x 7 cars, latent 4, fp32,
+synthetic lanes already in HBM.  N>1: every rank holds its own 4096-lane
+shard (weak scaling, global batch N*4096), gradients are all-reduced (RCCL)
+once per step.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# Chip peaks used for roofline fractions (MI355X, gfx950)
+PEAK_FP32_MATRIX_TFLOPS = 157.3     # dense f32 MFMA
+PEAK_HBM_GBS = 8000.0               # HBM3E
+
+
+def vae_flops_per_lane(N: int, g: int) -> float:
+    """Algorithmic training FLOPs per lane-sample: forward MACs
+    M = 12896*N + 16384 + 256*g (per-car layers x N, per-lane layers once),
+    x 2 FLOP/MAC x 3 (forward, input gradient, weight gradient)."""
+    return 6.0 * (12896.0 * N + 16384.0 + 256.0 * g)
+
+
+def synth_lanes(B: int, N: int, seed: int) -> np.ndarray:
+    rs = np.random.RandomState(seed)
+    x = rs.uniform(0.0, 1.0, size=(B, N, 1))
+    v = rs.uniform(0.0, 1.08, size=(B, N, 1))
+    return np.concatenate([x, v], axis=-1).astype(np.float32)
+
+
+def cpu_baseline_vae(B: int, N: int, g: int, budget_s: float = 12.0) -> dict:
+    """The CPU oracle (PyTorch fp32 restatement of the reference's
+    Encoder.learn) timed on this box's host cores on the same batch shape."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import hhrl_oracle as O
+    torch.manual_seed(0)
+    shapes = O.vae_param_shapes(g)
+    state = {}
+    fan = 1
+    for name, shp in shapes:
+        if len(shp) == 2:
+            fan = shp[1]
+        state[name] = (torch.rand(shp) * 2 - 1) / fan ** 0.5
+    vae = O.VAE(state, g)
+    x = synth_lanes(B, N, 1)
+    xl = x.tolist()                           # the reference's learn() receives a Python list
+    eps = torch.randn(B, g)
+    for _ in range(2):
+        vae.learn(xl, eps)
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        vae.learn(xl, eps)
+        steps += 1
+        if time.perf_counter() - t0 > budget_s and steps >= 5:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": B * steps / dt, "unit": "lane-samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d steps of the CPU oracle's Encoder.learn at B=%d N=%d g=%d (list->tensor included), %.1f s"
+                      % (steps, B, N, g, dt),
+            "ms_per_step": 1e3 * dt / steps}
+
+
+def agent_update_rates(device, steps: int) -> dict:
+    """Extra fields: TD3 update minibatches/s from synthetic replay
+    (WorkerTD3 row width 36 and HATD3Triple row width 1030, batch 64)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import gen
+    from hhrl_vae_amd.algorithm import HATD3Triple, WorkerTD3
+    out = {}
+    for name, net, n_rows in (("worker_td3_b64", WorkerTD3(gen.cav_cfg(cap=4096), device=str(device)), 4096),
+                              ("hatd3_triple_b64", HATD3Triple(gen.light_cfg(cap=2048), device=str(device)), 2048)):
+        rows = np.random.RandomState(3407).uniform(0, 1, size=(n_rows, net.fam.row_width))
+        net.memory[:n_rows] = rows
+        net.pointer = n_rows
+        for _ in range(4):
+            net.learn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            net.learn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[name] = {"minibatches_per_s": steps / dt, "ms_per_update": 1e3 * dt / steps}
+    return out
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4096, help="lanes per GPU")
+    ap.add_argument("--cars", type=int, default=7)
+    ap.add_argument("--latent", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-agents", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+        group = dist.group.WORLD
+
+    from hhrl_vae_amd import _lib
+    from hhrl_vae_amd.algorithm import Encoder
+
+    B, N, g = args.batch, args.cars, args.latent
+    enc = Encoder(2, g, device=str(device), seed=3407, group=group)
+    x = torch.from_numpy(synth_lanes(B, N, 3407 + rank)).to(device)
+    gcount = B * N * world
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        enc.learn(x, sync=False, global_count=gcount)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        enc.learn(x, sync=False, global_count=gcount)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    value = world * B * args.steps / dt
+
+    # per-kernel HIP-event timing over an identical region (events on the launch stream)
+    lib = _lib.load()
+    lib.hhrl_prof_reset()
+    lib.hhrl_prof_enable(1)
+    prof_steps = min(args.steps, 50)
+    for _ in range(prof_steps):
+        enc.learn(x, sync=False, global_count=gcount)
+    torch.cuda.synchronize()
+    lib.hhrl_prof_enable(0)
+    prof = _lib.prof_report()
+    lib.hhrl_prof_reset()
+
+    if rank == 0:
+        kernels = {k: dict(v, ms_per_step=v["ms"] / prof_steps) for k, v in prof.items()}
+        dom_name = max(kernels, key=lambda k: kernels[k]["ms"])
+        dom = kernels[dom_name]
+        mfma_bound = dom["flops"] > 0
+        if mfma_bound:
+            achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None}
+        else:
+            achieved = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": achieved / PEAK_HBM_GBS, "traffic": None}
+        roof["avg_launch_us"] = 1e3 * dom["ms"] / max(dom["launches"], 1)
+        roof["launches_per_step"] = dom["launches"] / prof_steps
+        step_alg_tflops = vae_flops_per_lane(N, g) * B / (dt / args.steps) / 1e12
+        gpu_ms_per_step = sum(v["ms"] for v in prof.values()) / prof_steps
+        out = {
+            "metric": "VAE train lane-samples/s", "value": value, "unit": "lane-samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "vae_train_b%d_n%d_g%d" % (B, N, g), "lanes_per_gpu": B, "cars_per_lane": N,
+                       "latent": g, "global_batch": B * world, "parallelism": "dp%d" % world},
+            "roofline": roof,
+            "step_algorithmic_tflops": step_alg_tflops,
+            "step_frac_of_fp32_matrix_peak": step_alg_tflops / PEAK_FP32_MATRIX_TFLOPS,
+            "gpu_kernel_ms_per_step": gpu_ms_per_step,
+            "kernels": {k: {"launches_per_step": v["launches"] / prof_steps, "ms_per_step": v["ms_per_step"]}
+                        for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])},
+        }
+        if world == 1 and not args.no_agents:
+            out["agent_updates"] = agent_update_rates(device, max(20, min(args.steps, 100)))
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_vae(B, N, g)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

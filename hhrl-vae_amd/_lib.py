@@ -40,6 +40,9 @@ SIGNATURES = {
     "hhrl_lstm_backward": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
     "hhrl_adam_step": (_I, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _I, _D, _P]),
     "hhrl_polyak_update": (_I, [_P, _P, _L, _D, _P]),
+    "hhrl_prof_enable": (_I, [_I]),
+    "hhrl_prof_reset": (_I, []),
+    "hhrl_prof_report": (_L, [C.c_char_p, _L]),
 }
 
 _lib = None
@@ -78,3 +81,17 @@ def stream_ptr() -> int:
     there so they order with torch's own copies and allocations."""
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+def prof_report() -> dict:
+    """{kernel name: {"launches", "ms", "flops", "bytes"}} since the last reset
+    (synchronises on the recorded events)."""
+    lib = load()
+    n = lib.hhrl_prof_report(None, 0)
+    buf = C.create_string_buffer(int(n) + 16)
+    lib.hhrl_prof_report(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, cnt, ms, fl, by = line.rsplit(" ", 4)
+        out[name] = {"launches": int(cnt), "ms": float(ms), "flops": float(fl), "bytes": float(by)}
+    return out

@@ -61,6 +61,18 @@ __device__ __forceinline__ float act_grad_from_output(float y, int act) {
 
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Optional per-launch timing (off by default).  When enabled through
+// hhrl_prof_enable(1), every kernel launch site brackets its launch with a
+// pair of HIP events recorded on the launch stream and notes the algorithmic
+// work (flops, bytes) of that launch; hhrl_prof_report() aggregates by name.
+bool prof_on();
+struct ProfScope {
+  ProfScope(const char* name, hipStream_t st, double flops, double bytes);
+  ~ProfScope();
+  int slot;
+  hipStream_t st;
+};
+
 // Internal GEMM front door (gemm.hip):  C[i][j] (op)= sum_k A(i,k) * B(k,j)
 //   A(i,k) = A[i*a_si + k*a_sk],  B(k,j) = B[k*b_sk + j*b_sj]
 // mode 0: C = act(acc + bias[j]); mode 1: C = act(C + acc + bias[j]);

@@ -170,6 +170,7 @@ extern "C" {
 int hhrl_vae_reparam(const float* ml, const float* eps, float* z, int B, int g, void* stream) {
   HHRL_REQUIRE(ml && eps && z, "vae_reparam: null pointer");
   HHRL_REQUIRE(B > 0 && g > 0, "vae_reparam: bad shape B=%d g=%d", B, g);
+  ProfScope ps("vae_reparam_kernel", as_stream(stream), 0.0, 12.0 * B * g * 4 / 3);
   hipLaunchKernelGGL(vae_reparam_kernel, dim3(ceil_div((long)B * g, 256)), dim3(256), 0, as_stream(stream), ml, eps, z, B, g);
   return launch_status("vae_reparam_kernel");
 }
@@ -181,6 +182,7 @@ int hhrl_vae_elbo(const float* decoded, const float* data, const float* ml, floa
   const long bn = (long)B * N;
   HHRL_REQUIRE(bn < (1L << 30), "vae_elbo: B*N too large");
   const int grid = stream_grid(bn > (long)B * g ? bn : (long)B * g);
+  ProfScope ps("vae_elbo_kernel", as_stream(stream), 0.0, 4.0 * (3.0 * bn + 2.0 * B * g));
   hipLaunchKernelGGL(vae_elbo_kernel, dim3(grid), dim3(256), 0, as_stream(stream), decoded, data, ml, recon_scale, loss,
                      d_decoded, (int)bn, B * g, g);
   return launch_status("vae_elbo_kernel");
@@ -189,6 +191,7 @@ int hhrl_vae_elbo(const float* decoded, const float* data, const float* ml, floa
 int hhrl_vae_latent_grad(const float* dz, const float* ml, const float* eps, float* d_ml, int B, int g, void* stream) {
   HHRL_REQUIRE(dz && ml && eps && d_ml, "vae_latent_grad: null pointer");
   HHRL_REQUIRE(B > 0 && g > 0, "vae_latent_grad: bad shape B=%d g=%d", B, g);
+  ProfScope ps("vae_latent_grad_kernel", as_stream(stream), 0.0, 24.0 * B * g);
   hipLaunchKernelGGL(vae_latent_grad_kernel, dim3(ceil_div((long)B * g, 256)), dim3(256), 0, as_stream(stream), dz, ml, eps, d_ml, B, g);
   return launch_status("vae_latent_grad_kernel");
 }
@@ -196,6 +199,7 @@ int hhrl_vae_latent_grad(const float* dz, const float* ml, const float* eps, flo
 int hhrl_td3_smooth_action(const float* pi, int ldp, const float* eps, float* out, int ldo, int B, int a, void* stream) {
   HHRL_REQUIRE(pi && eps && out, "td3_smooth_action: null pointer");
   HHRL_REQUIRE(B > 0 && a > 0 && ldp >= a && ldo >= a, "td3_smooth_action: bad shape B=%d a=%d ldp=%d ldo=%d", B, a, ldp, ldo);
+  ProfScope ps("td3_smooth_action_kernel", as_stream(stream), 0.0, 12.0 * B * a);
   hipLaunchKernelGGL(td3_smooth_action_kernel, dim3(ceil_div((long)B * a, 256)), dim3(256), 0, as_stream(stream), pi, ldp, eps, out, ldo, B, a);
   return launch_status("td3_smooth_action_kernel");
 }
@@ -204,6 +208,7 @@ int hhrl_td3_target_q(const float* q1, const float* q2, const float* r, int ldr,
                       void* stream) {
   HHRL_REQUIRE(q1 && q2 && r && y, "td3_target_q: null pointer");
   HHRL_REQUIRE(B > 0 && ldr >= 1, "td3_target_q: B=%d ldr=%d", B, ldr);
+  ProfScope ps("td3_target_q_kernel", as_stream(stream), 0.0, 16.0 * B);
   hipLaunchKernelGGL(td3_target_q_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, as_stream(stream), q1, q2, r, ldr, gamma, y, B);
   return launch_status("td3_target_q_kernel");
 }
@@ -212,6 +217,7 @@ int hhrl_twin_mse(const float* q1, const float* q2, const float* y, float inv_n,
                   int B, void* stream) {
   HHRL_REQUIRE(q1 && q2 && y && loss && dq1 && dq2, "twin_mse: null pointer");
   HHRL_REQUIRE(B > 0, "twin_mse: B=%d", B);
+  ProfScope ps("twin_mse_kernel", as_stream(stream), 0.0, 20.0 * B);
   hipLaunchKernelGGL(twin_mse_kernel, dim3(stream_grid(B)), dim3(256), 0, as_stream(stream), q1, q2, y, inv_n, loss, dq1, dq2, B);
   return launch_status("twin_mse_kernel");
 }
@@ -233,6 +239,7 @@ int hhrl_adam_step(float* p, const float* g, float* m, float* v, long n, double 
   k.eps = (float)eps;
   k.gscale = (float)grad_scale;
   hipStream_t st = as_stream(stream);
+  ProfScope ps("adam_kernel", st, 0.0, 28.0 * n);
   if (aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v)) {
     hipLaunchKernelGGL(adam_kernel, dim3(stream_grid((n + 3) / 4)), dim3(256), 0, st, p, g, m, v, n, k);
   } else {
@@ -245,6 +252,7 @@ int hhrl_polyak_update(float* target, const float* p, long n, double tau, void* 
   HHRL_REQUIRE(target && p, "polyak_update: null pointer");
   HHRL_REQUIRE(n > 0, "polyak_update: n=%ld", n);
   const int vec = aligned16(target) && aligned16(p);
+  ProfScope ps("polyak_kernel", as_stream(stream), 0.0, 12.0 * n);
   hipLaunchKernelGGL(polyak_kernel, dim3(stream_grid(vec ? (n + 3) / 4 : n)), dim3(256), 0, as_stream(stream), target, p, n,
                      (float)tau, (float)(1.0 - tau), vec);
   return launch_status("polyak_kernel");

@@ -137,6 +137,8 @@ int gemm(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b
     gz = ceil_div(K, chunk);
   }
   dim3 grid(gx, gy, gz), block(256);
+  static const char* const names[4] = {"gemm_mfma_kernel<1,1>", "gemm_mfma_kernel<1,2>", "gemm_mfma_kernel<2,1>", "gemm_mfma_kernel<2,2>"};
+  ProfScope ps(names[(TM - 1) * 2 + (TN - 1)], st, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + (double)M * N));
   if (TM == 2 && TN == 2) hipLaunchKernelGGL((gemm_mfma_kernel<2, 2>), grid, block, 0, st, g);
   else if (TM == 2) hipLaunchKernelGGL((gemm_mfma_kernel<2, 1>), grid, block, 0, st, g);
   else if (TN == 2) hipLaunchKernelGGL((gemm_mfma_kernel<1, 2>), grid, block, 0, st, g);

@@ -114,6 +114,7 @@ int hhrl_linear_backward(const float* x, int ldx, const float* w, const float* y
     const int rp = 256 / cw;
     int rows_per_block = rp * 16;
     dim3 grid(ceil_div(N, cw), ceil_div(M, rows_per_block));
+    ProfScope ps("act_grad_colsum_kernel", st, 2.0 * M * N, 4.0 * M * N * (act != HHRL_ACT_NONE ? 3 : 1));
     hipLaunchKernelGGL(act_grad_colsum_kernel, grid, dim3(256), 0, st, y, ldy, dy, lddy, db, M, N, act, cw,
                        rows_per_block);
     HHRL_TRY(launch_status("act_grad_colsum_kernel"));
@@ -126,6 +127,7 @@ int hhrl_linear_backward(const float* x, int ldx, const float* w, const float* y
 int hhrl_sum_pool(const float* in, int ldi, float* out, int ldo, int B, int N, int C, void* stream) {
   HHRL_REQUIRE(in && out, "sum_pool: null pointer");
   HHRL_REQUIRE(B > 0 && N > 0 && C > 0 && ldi >= C && ldo >= C, "sum_pool: bad shape B=%d N=%d C=%d ldi=%d ldo=%d", B, N, C, ldi, ldo);
+  ProfScope ps("sum_pool_kernel", as_stream(stream), 0.0, 4.0 * B * C * (N + 1));
   hipLaunchKernelGGL(sum_pool_kernel, dim3(ceil_div((long)B * C, 256)), dim3(256), 0, as_stream(stream), in, ldi, out, ldo, B, N, C);
   return launch_status("sum_pool_kernel");
 }
@@ -133,6 +135,7 @@ int hhrl_sum_pool(const float* in, int ldi, float* out, int ldo, int B, int N, i
 int hhrl_broadcast_rows(const float* in, int ldi, float* out, int ldo, int B, int N, int C, void* stream) {
   HHRL_REQUIRE(in && out, "broadcast_rows: null pointer");
   HHRL_REQUIRE(B > 0 && N > 0 && C > 0 && ldi >= C && ldo >= C, "broadcast_rows: bad shape B=%d N=%d C=%d ldi=%d ldo=%d", B, N, C, ldi, ldo);
+  ProfScope ps("broadcast_rows_kernel", as_stream(stream), 0.0, 4.0 * B * C * (N + 1));
   hipLaunchKernelGGL(broadcast_rows_kernel, dim3(ceil_div((long)B * N * C, 256)), dim3(256), 0, as_stream(stream), in, ldi, out, ldo, B, N, C);
   return launch_status("broadcast_rows_kernel");
 }
@@ -140,12 +143,14 @@ int hhrl_broadcast_rows(const float* in, int ldi, float* out, int ldo, int B, in
 int hhrl_copy2d(const float* in, int ldi, float* out, int ldo, int M, int C, void* stream) {
   HHRL_REQUIRE(in && out, "copy2d: null pointer");
   HHRL_REQUIRE(M > 0 && C > 0 && ldi >= C && ldo >= C, "copy2d: bad shape M=%d C=%d ldi=%d ldo=%d", M, C, ldi, ldo);
+  ProfScope ps("copy2d_kernel", as_stream(stream), 0.0, 8.0 * M * C);
   hipLaunchKernelGGL(copy2d_kernel, dim3(ceil_div((long)M * C, 256)), dim3(256), 0, as_stream(stream), in, ldi, out, ldo, M, C);
   return launch_status("copy2d_kernel");
 }
 
 int hhrl_fill(float* p, long n, float value, void* stream) {
   HHRL_REQUIRE(p && n > 0, "fill: null pointer or n <= 0");
+  ProfScope ps("fill_kernel", as_stream(stream), 0.0, 4.0 * n);
   hipLaunchKernelGGL(fill_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), p, n, value);
   return launch_status("fill_kernel");
 }

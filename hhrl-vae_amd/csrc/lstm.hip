@@ -149,6 +149,7 @@ int hhrl_lstm_forward(const float* obs, int ldobs, const float* const* params, f
     float* gt = w.gates + (long)t * B * G;
     if (t > 0) HHRL_TRY(gemm(w.hbuf + (long)t * BH, H, 1, w_hh, 1, H, gt, G, B, G, H, nullptr, HHRL_ACT_NONE, 1, st));
     const bool last = t == T - 1;
+    ProfScope ps("lstm_cell_forward_kernel", st, 0.0, 28.0 * BH);
     hipLaunchKernelGGL(lstm_cell_forward_kernel, dim3(ceil_div(BH, 256)), dim3(256), 0, st, gt, b_hh,
                        w.cbuf + (long)t * BH, w.cbuf + (long)(t + 1) * BH, w.hbuf + (long)(t + 1) * BH, H,
                        last ? w.cat : nullptr, 2 * H, B, H);
@@ -189,6 +190,7 @@ int hhrl_lstm_backward(const float* const* params, const float* d_out, int lddo,
   int lddh = 2 * H;
   for (int t = T - 1; t >= 0; --t) {
     float* dgt = w.dgates + (long)t * B * G;
+    ProfScope ps("lstm_cell_backward_kernel", st, 0.0, 48.0 * BH);
     hipLaunchKernelGGL(lstm_cell_backward_kernel, cell_grid, blk, 0, st, w.gates + (long)t * B * G,
                        w.cbuf + (long)t * BH, w.cbuf + (long)(t + 1) * BH, dh, lddh, w.dc, t == T - 1 ? 1 : 0, dgt, B, H);
     HHRL_TRY(launch_status("lstm_cell_backward_kernel"));

@@ -206,18 +206,26 @@ class Encoder:
         self._keep = (x, eps)           # keep inputs alive until the stream has consumed them
         return self._loss[0]
 
-    def learn(self, data, eps=None, sync: bool = True):
+    def learn(self, data, eps=None, sync: bool = True, global_count: Optional[int] = None):
         """Encoder.learn (algorithm.py:92-107): one Adam step on one batch of
         lanes that all hold N cars.  Returns the loss (float, or a device
-        scalar when sync=False)."""
+        scalar when sync=False).
+
+        Data-parallel (group set): `data` is this rank's shard; the squared
+        error is divided by the GLOBAL element count (`global_count`, or an
+        all-reduced count when omitted), KL stays a sum, and the flat gradient
+        buffer is all-reduced (SUM) once before the Adam step, so every rank
+        applies the single-device update for the global batch."""
         if self.group is None:
             loss = self.loss_and_grads(data, eps)
         else:
             import torch.distributed as dist
             x = self._to_device(data)
-            cnt = torch.tensor([float(x.shape[0] * x.shape[1])], device=self.device)
-            dist.all_reduce(cnt, group=self.group)
-            loss = self.loss_and_grads(x, eps, recon_count=int(cnt.item()))
+            if global_count is None:
+                cnt = torch.tensor([float(x.shape[0] * x.shape[1])], device=self.device)
+                dist.all_reduce(cnt, group=self.group)
+                global_count = int(cnt.item())
+            loss = self.loss_and_grads(x, eps, recon_count=global_count)
             dist.all_reduce(self.opt.g.data, group=self.group)          # one flat bucket, SUM
             loss = loss.clone()
             dist.all_reduce(loss, group=self.group)

@@ -143,6 +143,18 @@ int hhrl_adam_step(float* p, const float* g, float* m, float* v, long n, double 
 /* target = tau*p + (1-tau)*target          (algorithm.py:323-326, 534-539, 827-834, 1163-1166, 1361-1364) */
 int hhrl_polyak_update(float* target, const float* p, long n, double tau, void* stream);
 
+/* ------------------------------------------------------------- diagnostics
+ * Per-launch timing with HIP events recorded on the launch stream (no
+ * counterpart in the reference; used by bench.py for roofline figures).
+ * While enabled, every kernel launch inside the library is bracketed by two
+ * events and tagged with its algorithmic flops and bytes.
+ * hhrl_prof_report() SYNCHRONISES on the recorded events and writes one line
+ * per kernel name: "name launches total_ms total_flops total_bytes".  It
+ * returns the buffer size needed (including the terminating NUL). */
+int hhrl_prof_enable(int on);
+int hhrl_prof_reset(void);
+long hhrl_prof_report(char* buf, long cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -161,15 +161,18 @@ class StepLR:
 class VAE:
     """Functional twin of ``Encoder`` (algorithm.py:76-138)."""
 
-    def __init__(self, state: Params, goal_dim: int, lr: float = 1e-3):
+    def __init__(self, state: Params, goal_dim: int, lr: float = 1e-3, dtype=torch.float32):
+        """dtype=torch.float64 gives a high-precision yardstick for judging
+        fp32 summation noise; the oracle proper is fp32."""
         self.goal_dim = goal_dim
+        self.dtype = dtype
         self.names = [n for n, _ in vae_param_shapes(goal_dim)]
-        self.p: Params = {k: state[k].detach().clone().float().requires_grad_(True) for k in self.names}
+        self.p: Params = {k: state[k].detach().clone().to(dtype).requires_grad_(True) for k in self.names}
         self.opt = Adam([self.p[k] for k in self.names], lr)
         self.grads: Params = {}
 
     def loss_and_grads(self, data: Tensor, eps: Tensor, recon_count=None):
-        loss = vae_loss(self.p, data, eps, recon_count)
+        loss = vae_loss(self.p, data.to(self.dtype), eps.to(self.dtype), recon_count)
         g = torch.autograd.grad(loss, [self.p[k] for k in self.names])
         return loss.detach(), dict(zip(self.names, g))
 
