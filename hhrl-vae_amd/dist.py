@@ -1,0 +1,49 @@
+"""Data-parallel plumbing: one process per GPU, `torch.distributed` (backend
+"nccl" = RCCL over xGMI on the GPUs, "gloo" in CPU tests).
+
+The learning path shards by minibatch rows and has ONE exchange step per
+optimizer step: a SUM all-reduce of the flat gradient buffer.  Loss terms that
+are means over the batch are divided by the GLOBAL count on every shard, terms
+that are sums are left alone, so that the summed shard gradients equal the
+single-device gradient of the global batch and every rank applies the same
+Adam update to its replica.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+
+def world(group) -> Tuple[int, int]:
+    """(rank, world_size) of `group`; (0, 1) without a group."""
+    if group is None:
+        return 0, 1
+    import torch.distributed as dist
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def shard_bounds(n_rows: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Rows [lo, hi) of a global batch owned by `rank`: contiguous, sizes
+    differ by at most one, every row owned exactly once."""
+    base, rem = divmod(n_rows, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def global_count(local_count: int, group, device=None) -> int:
+    """Sum of `local_count` over the group (one tiny all-reduce + host read)."""
+    if group is None:
+        return int(local_count)
+    import torch.distributed as dist
+    t = torch.tensor([float(local_count)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, group=group)
+    return int(round(float(t.item())))
+
+
+def allreduce_sum_(flat: torch.Tensor, group) -> torch.Tensor:
+    """In-place SUM all-reduce of one flat fp32 bucket (no-op without a group)."""
+    if group is not None:
+        import torch.distributed as dist
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return flat

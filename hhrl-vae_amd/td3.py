@@ -394,8 +394,8 @@ class TD3Learner:
 
     def _allreduce(self, g: FlatBuffer) -> None:
         if self.group is not None:
-            import torch.distributed as dist
-            dist.all_reduce(g.data, group=self.group)
+            from . import dist as hdist
+            hdist.allreduce_sum_(g.data, self.group)
 
     def _learn(self, indices=None, noise=None, order=None) -> None:
         if indices is None:

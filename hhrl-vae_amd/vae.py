@@ -219,16 +219,13 @@ class Encoder:
         if self.group is None:
             loss = self.loss_and_grads(data, eps)
         else:
-            import torch.distributed as dist
+            from . import dist as hdist
             x = self._to_device(data)
             if global_count is None:
-                cnt = torch.tensor([float(x.shape[0] * x.shape[1])], device=self.device)
-                dist.all_reduce(cnt, group=self.group)
-                global_count = int(cnt.item())
+                global_count = hdist.global_count(int(x.shape[0] * x.shape[1]), self.group, self.device)
             loss = self.loss_and_grads(x, eps, recon_count=global_count)
-            dist.all_reduce(self.opt.g.data, group=self.group)          # one flat bucket, SUM
-            loss = loss.clone()
-            dist.all_reduce(loss, group=self.group)
+            hdist.allreduce_sum_(self.opt.g.data, self.group)           # one flat bucket, SUM
+            loss = hdist.allreduce_sum_(loss.clone(), self.group)
         self.opt.step()                                                 # :106
         return float(loss.item()) if sync else loss.clone()
 

@@ -1,0 +1,99 @@
+"""Host-side logic that needs no GPU: flat buffer layouts, the StepLR rule,
+the VAE batch loop's bucketing, family shapes, replay layouts."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import gen
+import hhrl_oracle as O
+from golden_util import load_case, sub
+
+
+def test_flat_layout_and_views():
+    from hhrl_vae_amd.flat import ALIGN, FlatBuffer, Layout
+    from hhrl_vae_amd.vae import vae_shapes
+    for g, n_params in ((2, 30389), (4, 30905), (8, 31937), (16, 34001)):      # parameter counts of Encoder(2, g)
+        lay = Layout(vae_shapes(g))
+        assert lay.numel() == n_params and len(lay.names) == 24
+        assert all(off % ALIGN == 0 for off in lay.offsets.values()) and lay.size % ALIGN == 0
+    lay = Layout(vae_shapes(4))
+    assert [n for n, _ in O.vae_param_shapes(4)] == lay.names
+    fb = FlatBuffer(lay, "cpu")
+    init = gen.gen_state(vae_shapes(4), 1)
+    fb.load(init)
+    for k, v in fb.state_dict().items():
+        assert np.array_equal(v.numpy(), init[k])
+    fb["encoder.phi.0.bias"].fill_(2.0)                        # views alias the flat storage
+    off = lay.offsets["encoder.phi.0.bias"]
+    assert torch.all(fb.data[off: off + 16] == 2.0) and float(fb.data[off + 16]) == 0.0
+    with pytest.raises(KeyError):
+        fb.load({"nope": np.zeros(3)})
+    with pytest.raises(ValueError):
+        fb.load(dict(init, **{"encoder.phi.0.bias": np.zeros(3, dtype=np.float32)}))
+
+
+def test_family_shapes_match_reference_counts():
+    from hhrl_vae_amd.flat import Layout
+    from hhrl_vae_amd.spec import actor_shapes, critic_shapes, family_from_cfg
+    light, cav = gen.light_cfg(), gen.cav_cfg()
+    fam = family_from_cfg("triple", light)
+    assert [Layout(actor_shapes(fam, k)).numel() for k in range(3)] == [351529, 352432, 364720]
+    assert Layout(critic_shapes(fam)).numel() == 1216898 and fam.row_width == 1030 and fam.critic_in == 393
+    w = family_from_cfg("worker", cav)
+    assert Layout(actor_shapes(w, 0)).numel() == 18945 and Layout(critic_shapes(w)).numel() == 38146 and w.row_width == 36
+    assert Layout(critic_shapes(family_from_cfg("single", light, "time"))).numel() == 524530
+    assert Layout(critic_shapes(family_from_cfg("manager", light))).numel() == 539218
+    assert Layout(critic_shapes(family_from_cfg("double", light, "time"))).numel() == 902402
+    assert Layout(critic_shapes(family_from_cfg("tp", light))).numel() == 890114
+    for kind, task, cfg in (("triple", None, light), ("worker", None, cav), ("double", "phase", light), ("tp", None, light),
+                            ("manager", None, light), ("single", "time", light)):
+        f, of = family_from_cfg(kind, cfg, task), O.family_from_cfg(kind, cfg, task)
+        for k in range(len(f.a_dims)):
+            assert actor_shapes(f, k) == O.actor_param_shapes(of, k)
+        assert critic_shapes(f) == O.critic_param_shapes(of)
+        assert f.row_width == of.row_width
+
+
+def test_steplr_rule_matches_torch():
+    from hhrl_vae_amd.optim import StepLR
+
+    class FakeOpt:
+        lr = base_lr = 1e-3
+    p = torch.nn.Parameter(torch.zeros(1))
+    topt = torch.optim.Adam([p], lr=1e-3)
+    tsch = torch.optim.lr_scheduler.StepLR(topt, step_size=3, gamma=0.5)
+    fo = FakeOpt()
+    sch = StepLR(fo, 3)
+    for _ in range(11):
+        topt.step()
+        tsch.step()
+        sch.step()
+        assert fo.lr == pytest.approx(topt.param_groups[0]["lr"], rel=1e-15)
+
+
+def test_vae_chunking_matches_golden_loop():
+    from hhrl_vae_amd.vae_train import chunk_dataset, shuffle_chunks
+    fx = load_case("vae_loop_g2")
+    dataset = {k: v.tolist() for k, v in sub(fx, "bucket").items()}
+    chunks = chunk_dataset(dataset, int(fx["batch_size"]))
+    assert [len(chunks[i]) for i in fx["order"]] == fx["chunk_sizes"].tolist()
+    assert chunks == O.vae_chunk_dataset(dataset, int(fx["batch_size"]))
+    assert all(len({len(lane) for lane in c}) == 1 for c in chunks)            # one car count per chunk
+    a = shuffle_chunks(chunks, random.Random(3407))
+    order = list(range(len(chunks)))
+    random.Random(3407).shuffle(order)
+    assert a == [chunks[i] for i in order] and order == fx["order"].tolist()
+    assert chunk_dataset({"3": [], "1": [[[0.1, 0.2]]]}, 64) == [[[[0.1, 0.2]]]]
+
+
+def test_shard_bounds_cover_batch_once():
+    from hhrl_vae_amd.dist import shard_bounds
+    for n in (1, 7, 64, 4096, 4097):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
