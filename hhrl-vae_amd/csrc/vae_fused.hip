@@ -1,0 +1,1011 @@
+// Fused DeepSets-VAE training step for gfx950: four launches per step.
+//
+//   vae_lane_forward   per traffic lane: phi (per car, pooled), rho, heads,
+//                      reparameterisation, latent branch of the decoder
+//   vae_car_fwd_bwd    per car: loc embedding, func.0/2/4, squared error, and
+//                      the whole backward of those layers (85 % of the FLOPs)
+//   vae_lane_backward  per traffic lane: backward of everything in the first
+//                      kernel, KL gradient included
+//   vae_reduce_grads   fixed-order sum of the per-workgroup gradient slabs
+//
+// Every matrix product runs on v_mfma_f32_32x32x2_f32 with BOTH operands read
+// from LDS "images": activations as [row][feature] with an odd row stride,
+// weights as [out][in] with an odd row stride.  With those strides the three
+// products of a layer (forward, input gradient, weight gradient) all read
+// their operands conflict-free from the same images, and an accumulator tile
+// (rows on registers, columns on lanes) is written back conflict-free.
+// Weight-gradient tiles stay in accumulator registers across a workgroup's
+// tiles and are written once, to that workgroup's slab; nothing is atomically
+// accumulated except the [B,32] latent gradient that crosses tile boundaries.
+#include "common.h"
+
+namespace hhrl {
+namespace vf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// parameter order == Encoder.parameters() order (weight, bias interleaved)
+enum { PHI0 = 0, PHI2, RHO0, RHO2, MEAN, LOGVAR, DEC0, DEC2, LOC, FUNC0, FUNC2, FUNC4, NLAYER };
+
+struct Offsets {
+  long w[NLAYER], b[NLAYER];
+  long total;
+};
+
+__device__ __forceinline__ int drow(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+__device__ __forceinline__ void wave_sync() {
+  // LDS traffic of one wave is processed in order; this only stops the
+  // compiler from moving LDS accesses across the hand-off point.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ f32x16 splat(float v) {
+  f32x16 r;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) r[i] = v;
+  return r;
+}
+
+// acc[t] += A[32 x K] * B[K x 32] for TJ column tiles, operands in LDS:
+//   A(i,k) = a[i*ASI + k*ASK]      B(k, 32*t + j) = b[k*BSK + (32*t + j)*BSJ]
+template <int TJ, int K, int ASI, int ASK, int BSK, int BSJ>
+__device__ __forceinline__ void wave_mma(f32x16 (&acc)[TJ], const float* a, const float* b, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const float* ap = a + r * ASI + h * ASK;
+  const float* bp = b + h * BSK + r * BSJ;
+#pragma unroll
+  for (int k = 0; k < K; k += 2) {
+    const float av = ap[k * ASK];
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) {
+      const float bv = bp[k * BSK + t * 32 * BSJ];
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+    }
+  }
+}
+
+// Store a D tile into an image: img[row][col0 + lane&31], rows = drow(reg, h).
+template <int LD>
+__device__ __forceinline__ void store_tile(float* img, int col0, const f32x16& t, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) img[drow(i, h) * LD + col0 + r] = t[i];
+}
+
+// Copy a [rows][cols] row-major global matrix into an LDS image with row stride LD.
+__device__ __forceinline__ void load_weight(float* img, int ld, const float* __restrict__ w, int rows, int cols, int tid, int nthreads) {
+  for (int idx = tid; idx < rows * cols; idx += nthreads) {
+    const int r = idx / cols, c = idx - r * cols;
+    img[r * ld + c] = w[idx];
+  }
+}
+
+// ===================================================================== per-car kernel
+struct CarArgs {
+  const float* data;  // [rows][2]  (loc, v)
+  const float* d2;    // [B][32]
+  const float *wloc, *bloc, *w0, *b0, *w2, *b2, *w4, *b4;
+  float* d_d2;        // [B][32], zeroed by the caller, atomically accumulated
+  float* slab;        // [gridDim.x][total]
+  float* loss_part;   // [gridDim.x]
+  Offsets off;
+  long rows;          // B*N
+  int N, tiles;
+  float recon_scale;
+};
+
+constexpr int CAR_W0 = 0;                         // [128][65]
+constexpr int CAR_W2 = CAR_W0 + 128 * 65;         // [32][129]
+constexpr int CAR_SMALL = CAR_W2 + 32 * 129;      // b0[128] b2[32] w4[32] wloc[32] bloc[32] b4[1]
+constexpr int CAR_WAVE0 = CAR_SMALL + 320;
+constexpr int CAR_CAT = 0;                        // per wave: [32][65]
+constexpr int CAR_HALF = CAR_CAT + 32 * 65;       // [32][65]
+constexpr int CAR_F2 = CAR_HALF + 32 * 65;        // [32][33]
+constexpr int CAR_ROW = CAR_F2 + 32 * 33;         // loc[32] v[32] dpre[32] laneidx[32]
+constexpr int CAR_WAVE_FLOATS = CAR_ROW + 128;
+constexpr int CAR_LDS_FLOATS = CAR_WAVE0 + 4 * CAR_WAVE_FLOATS;
+
+__global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+
+  float* W0s = lds + CAR_W0;
+  float* W2s = lds + CAR_W2;
+  float* b0s = lds + CAR_SMALL;
+  float* b2s = b0s + 128;
+  float* w4s = b2s + 32;
+  float* wlocs = w4s + 32;
+  float* blocs = wlocs + 32;
+  float* b4s = blocs + 32;
+  load_weight(W0s, 65, g.w0, 128, 64, tid, 256);
+  load_weight(W2s, 129, g.w2, 32, 128, tid, 256);
+  if (tid < 128) b0s[tid] = g.b0[tid];
+  if (tid < 32) {
+    b2s[tid] = g.b2[tid];
+    w4s[tid] = g.w4[tid];
+    wlocs[tid] = g.wloc[tid];
+    blocs[tid] = g.bloc[tid];
+  }
+  if (tid == 0) b4s[0] = g.b4[0];
+  __syncthreads();
+
+  float* wl = lds + CAR_WAVE0 + wave * CAR_WAVE_FLOATS;
+  float* cat = wl + CAR_CAT;
+  float* half = wl + CAR_HALF;
+  float* f2i = wl + CAR_F2;
+  float* locs = wl + CAR_ROW;
+  float* vs = locs + 32;
+  float* dpre = vs + 32;
+  int* lidx = reinterpret_cast<int*>(dpre + 32);
+
+  f32x16 dW0[4][2], dW2[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    dW0[a][0] = splat(0.f);
+    dW0[a][1] = splat(0.f);
+    dW2[a] = splat(0.f);
+  }
+  float db0[4] = {0.f, 0.f, 0.f, 0.f};
+  float w4acc = 0.f, db2acc = 0.f, wlocacc = 0.f, blocacc = 0.f, b4acc = 0.f, lossacc = 0.f;
+
+  for (int tile = blockIdx.x * 4 + wave; tile < g.tiles; tile += gridDim.x * 4) {
+    const long row = (long)tile * 32 + r;
+    const bool valid = row < g.rows;
+    const float loc = valid ? g.data[row * 2] : 0.f;
+    const float v = valid ? g.data[row * 2 + 1] : 0.f;
+    const int bidx = valid ? (int)(row / g.N) : -1;
+    if (h == 0) {
+      locs[r] = loc;
+      vs[r] = v;
+      lidx[r] = bidx;
+    }
+    // cat image: [d2 of the car's lane | loc embedding]
+    if (h == 0) {
+      const float* src = g.d2 + (long)(valid ? bidx : 0) * 32;
+#pragma unroll 8
+      for (int k = 0; k < 32; ++k) cat[r * 65 + k] = valid ? src[k] : 0.f;
+    } else {
+#pragma unroll 8
+      for (int k = 0; k < 32; ++k) cat[r * 65 + 32 + k] = valid ? loc * wlocs[k] + blocs[k] : 0.f;
+    }
+    wave_sync();
+
+    // ---- forward: func.0 (64 -> 128, ReLU)
+    f32x16 f1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) f1[t] = splat(b0s[t * 32 + r]);
+    wave_mma<4, 64, 65, 1, 1, 65>(f1, cat, W0s, lane);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) f1[t][i] = fmaxf(f1[t][i], 0.f);
+
+    // ---- forward: func.2 (128 -> 32, ReLU), f1 staged through the half image 64 features at a time
+    f32x16 f2[1];
+    f2[0] = splat(b2s[r]);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      store_tile<65>(half, 0, f1[2 * hh], lane);
+      store_tile<65>(half, 32, f1[2 * hh + 1], lane);
+      wave_sync();
+      wave_mma<1, 64, 65, 1, 1, 129>(f2, half, W2s + 64 * hh, lane);
+      wave_sync();
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) f2[0][i] = fmaxf(f2[0][i], 0.f);
+    store_tile<33>(f2i, 0, f2[0], lane);
+    wave_sync();
+
+    // ---- forward: func.4 (32 -> 1, sigmoid), squared error and its gradient per car
+    {
+      float s = 0.f;
+#pragma unroll
+      for (int n = 0; n < 16; ++n) s += w4s[16 * h + n] * f2i[r * 33 + 16 * h + n];
+      s += __shfl_xor(s, 32, 64);
+      s += b4s[0];
+      const float out = 1.f / (1.f + expf(-s));
+      const float d = out - v;
+      float dp = 0.f;
+      if (valid) {
+        if (h == 0) lossacc += g.recon_scale * d * d;
+        dp = 2.f * g.recon_scale * d * out * (1.f - out);
+      }
+      if (h == 0) {
+        dpre[r] = dp;
+        b4acc += dp;
+      }
+    }
+    wave_sync();
+
+    // ---- backward func.4 / ReLU of func.2: dW4, db2 and df2 (in place over the f2 image)
+    {
+      const float w4n = w4s[r];
+#pragma unroll 4
+      for (int rr = 16 * h; rr < 16 * h + 16; ++rr) {
+        const float fv = f2i[rr * 33 + r];
+        const float dp = dpre[rr];
+        w4acc += dp * fv;
+        const float df = fv > 0.f ? dp * w4n : 0.f;
+        db2acc += df;
+        f2i[rr * 33 + r] = df;
+      }
+    }
+    wave_sync();
+
+    // ---- backward func.2: dW2 += df2^T f1 ; df1 = (df2 W2) o relu'(f1)
+    //      backward func.0: dW0 += df1^T cat ; dcat = df1 W0        (64 features of f1 at a time)
+    f32x16 dcat[2];
+    dcat[0] = splat(0.f);
+    dcat[1] = splat(0.f);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      store_tile<65>(half, 0, f1[2 * hh], lane);
+      store_tile<65>(half, 32, f1[2 * hh + 1], lane);
+      wave_sync();
+      {
+        f32x16 acc[2] = {dW2[2 * hh], dW2[2 * hh + 1]};
+        wave_mma<2, 32, 1, 33, 65, 1>(acc, f2i, half, lane);
+        dW2[2 * hh] = acc[0];
+        dW2[2 * hh + 1] = acc[1];
+      }
+      f32x16 df1[2];
+      df1[0] = splat(0.f);
+      df1[1] = splat(0.f);
+      wave_mma<2, 32, 33, 1, 129, 1>(df1, f2i, W2s + 64 * hh, lane);
+      wave_sync();                         // all reads of the f1 half image are done
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float cs = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float dv = f1[2 * hh + t][i] > 0.f ? df1[t][i] : 0.f;
+          df1[t][i] = dv;
+          cs += dv;
+        }
+        db0[2 * hh + t] += cs;
+      }
+      store_tile<65>(half, 0, df1[0], lane);
+      store_tile<65>(half, 32, df1[1], lane);
+      wave_sync();
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        f32x16 acc[2] = {dW0[2 * hh + it][0], dW0[2 * hh + it][1]};
+        wave_mma<2, 32, 1, 65, 65, 1>(acc, half + 32 * it, cat, lane);
+        dW0[2 * hh + it][0] = acc[0];
+        dW0[2 * hh + it][1] = acc[1];
+      }
+      wave_mma<2, 64, 65, 1, 65, 1>(dcat, half, W0s + 64 * hh * 65, lane);
+      wave_sync();
+    }
+
+    // ---- loc embedding gradients from dcat[:, 32:64]
+    {
+      float sb = 0.f, sw = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        sb += dcat[1][i];
+        sw += dcat[1][i] * locs[drow(i, h)];
+      }
+      blocacc += sb;
+      wlocacc += sw;
+    }
+    // ---- latent gradient: d_d2[lane] += sum over that lane's cars of dcat[:, 0:32]
+    store_tile<33>(half, 0, dcat[0], lane);
+    wave_sync();
+    {
+      int prev = lidx[16 * h];
+      float s = 0.f;
+#pragma unroll 4
+      for (int rr = 16 * h; rr < 16 * h + 16; ++rr) {
+        const int b = lidx[rr];
+        if (b != prev) {
+          if (prev >= 0) unsafeAtomicAdd(&g.d_d2[(long)prev * 32 + r], s);
+          prev = b;
+          s = 0.f;
+        }
+        s += half[rr * 33 + r];
+      }
+      if (prev >= 0) unsafeAtomicAdd(&g.d_d2[(long)prev * 32 + r], s);
+    }
+    wave_sync();
+  }
+
+  // ---- combine the two lane halves (they hold different rows of the same columns)
+#pragma unroll
+  for (int t = 0; t < 4; ++t) db0[t] += __shfl_xor(db0[t], 32, 64);
+  w4acc += __shfl_xor(w4acc, 32, 64);
+  db2acc += __shfl_xor(db2acc, 32, 64);
+  blocacc += __shfl_xor(blocacc, 32, 64);
+  wlocacc += __shfl_xor(wlocacc, 32, 64);
+  b4acc = wave_sum(b4acc);
+  lossacc = wave_sum(lossacc);
+
+  // ---- combine the four waves in LDS (fixed order), then one coalesced slab write
+  __syncthreads();
+  float* buf = lds + CAR_WAVE0;
+  constexpr int B_W0 = 0, B_B0 = 8192, B_W2 = B_B0 + 128, B_B2 = B_W2 + 4096, B_W4 = B_B2 + 32, B_B4 = B_W4 + 32;
+  constexpr int B_WLOC = B_B4 + 1, B_BLOC = B_WLOC + 32, B_LOSS = B_BLOC + 32, B_END = B_LOSS + 1;
+  static_assert(B_END <= 4 * CAR_WAVE_FLOATS, "combine buffer must fit in the wave regions");
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+      const bool first = w == 0;
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            float* p = buf + B_W0 + (it * 32 + drow(i, h)) * 64 + jt * 32 + r;
+            *p = first ? dW0[it][jt][i] : *p + dW0[it][jt][i];
+          }
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float* p = buf + B_W2 + drow(i, h) * 128 + jt * 32 + r;
+          *p = first ? dW2[jt][i] : *p + dW2[jt][i];
+        }
+      if (h == 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float* p = buf + B_B0 + t * 32 + r;
+          *p = first ? db0[t] : *p + db0[t];
+        }
+        float* p;
+        p = buf + B_B2 + r;   *p = first ? db2acc : *p + db2acc;
+        p = buf + B_W4 + r;   *p = first ? w4acc : *p + w4acc;
+        p = buf + B_WLOC + r; *p = first ? wlocacc : *p + wlocacc;
+        p = buf + B_BLOC + r; *p = first ? blocacc : *p + blocacc;
+        if (r == 0) {
+          p = buf + B_B4;   *p = first ? b4acc : *p + b4acc;
+          p = buf + B_LOSS; *p = first ? lossacc : *p + lossacc;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* slab = g.slab + (long)blockIdx.x * g.off.total;
+  for (int i = tid; i < 8192; i += 256) slab[g.off.w[FUNC0] + i] = buf[B_W0 + i];
+  for (int i = tid; i < 4096; i += 256) slab[g.off.w[FUNC2] + i] = buf[B_W2 + i];
+  if (tid < 128) slab[g.off.b[FUNC0] + tid] = buf[B_B0 + tid];
+  if (tid < 32) {
+    slab[g.off.b[FUNC2] + tid] = buf[B_B2 + tid];
+    slab[g.off.w[FUNC4] + tid] = buf[B_W4 + tid];
+    slab[g.off.w[LOC] + tid] = buf[B_WLOC + tid];
+    slab[g.off.b[LOC] + tid] = buf[B_BLOC + tid];
+  }
+  if (tid == 0) {
+    slab[g.off.b[FUNC4]] = buf[B_B4];
+    g.loss_part[blockIdx.x] = buf[B_LOSS];
+  }
+}
+
+// ===================================================================== per-lane kernels
+struct LaneArgs {
+  const float* data;   // [B*N][2]
+  const float* eps;    // [B][g]
+  const float* w[NLAYER];
+  const float* b[NLAYER];
+  // saved activations, [B][.]
+  float *h1s, *pooled, *r1, *r2, *ml, *z, *d1, *d2;
+  const float* d_d2;   // backward input
+  float* slab;
+  float* kl_part;      // [gridDim.x]
+  Offsets off;
+  int B, N, g, tiles;
+};
+
+// image slots (floats) shared by the four waves of a workgroup
+constexpr int LN_WS = 0;                       // weight slot: up to [64][129]
+constexpr int LN_BIAS = LN_WS + 64 * 129;      // 128
+constexpr int LN_A = LN_BIAS + 128;            // [32][129]
+constexpr int LN_B = LN_A + 32 * 129;          // [32][129]
+constexpr int LN_C = LN_B + 32 * 129;          // [32][65]
+constexpr int LN_D = LN_C + 32 * 65;           // [32][65]
+constexpr int LN_E = LN_D + 32 * 65;           // [32][33]
+constexpr int LN_F = LN_E + 32 * 33;           // [32][33]
+constexpr int LN_G = LN_F + 32 * 33;           // [32][33]
+constexpr int LN_H = LN_G + 32 * 33;           // [32][33]
+constexpr int LN_LDS_FLOATS = LN_H + 32 * 33;
+
+// Copy rows [row0, row0+32) of a [B][cols] global matrix into an image (zeros beyond B).
+__device__ __forceinline__ void load_rows(float* img, int ld, const float* __restrict__ src, int cols, int row0, int B, int tid) {
+  for (int idx = tid; idx < 32 * cols; idx += 256) {
+    const int rr = idx / cols, c = idx - rr * cols;
+    img[rr * ld + c] = (row0 + rr < B) ? src[(long)(row0 + rr) * cols + c] : 0.f;
+  }
+}
+__device__ __forceinline__ void store_rows(const float* img, int ld, float* dst, int cols, int row0, int B, int tid) {
+  for (int idx = tid; idx < 32 * cols; idx += 256) {
+    const int rr = idx / cols, c = idx - rr * cols;
+    if (row0 + rr < B) dst[(long)(row0 + rr) * cols + c] = img[rr * ld + c];
+  }
+}
+__device__ __forceinline__ void zero_img(float* img, int n, int tid) {
+  for (int idx = tid; idx < n; idx += 256) img[idx] = 0.f;
+}
+
+__global__ __launch_bounds__(256, 1) void vae_lane_forward_kernel(LaneArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31;
+  float* WS = lds + LN_WS;
+  float* BS = lds + LN_BIAS;
+  float* Ir1 = lds + LN_A;     // [32][129]
+  float* Id1 = lds + LN_B;     // [32][129]
+  float* Ir2 = lds + LN_C;     // [32][65]
+  float* Ih1 = lds + LN_D;     // [32][17] inside a 65-wide slot
+  float* Ipool = lds + LN_E;   // [32][33]
+  float* Iml = lds + LN_F;     // [32][33]
+  float* Iz = lds + LN_G;      // [32][17]
+  float* Id2 = lds + LN_H;     // [32][33]
+  const int gd = g.g;
+
+  for (int tile = blockIdx.x; tile < g.tiles; tile += gridDim.x) {
+    const int row0 = tile * 32;
+    __syncthreads();
+    // ---- phi.0 + ReLU summed over the lane's cars: h1s[lane][k] = sum_n relu(W0[k] . x_n + b0[k])
+    for (int idx = tid; idx < 32 * 16; idx += 256) {
+      const int rr = idx >> 4, k = idx & 15;
+      const int b = row0 + rr;
+      float s = 0.f;
+      if (b < g.B) {
+        const float wa = g.w[PHI0][2 * k], wb = g.w[PHI0][2 * k + 1], bb = g.b[PHI0][k];
+        const float* x = g.data + (long)b * g.N * 2;
+        for (int n = 0; n < g.N; ++n) s += fmaxf(wa * x[2 * n] + wb * x[2 * n + 1] + bb, 0.f);
+      }
+      Ih1[rr * 17 + k] = s;
+    }
+    // ---- phi.2 on the pooled hidden: pooled = W2 * h1s + N*b2   (1 column tile, K=16)
+    load_weight(WS, 17, g.w[PHI2], 32, 16, tid, 256);
+    if (tid < 32) BS[tid] = g.b[PHI2][tid];
+    __syncthreads();
+    if (wave == 0) {
+      f32x16 acc[1];
+      acc[0] = splat((float)g.N * BS[r]);
+      wave_mma<1, 16, 17, 1, 1, 17>(acc, Ih1, WS, lane);
+      store_tile<33>(Ipool, 0, acc[0], lane);
+    }
+    __syncthreads();
+    // ---- rho.0 (32 -> 128, ReLU): one column tile per wave
+    load_weight(WS, 33, g.w[RHO0], 128, 32, tid, 256);
+    if (tid < 128) BS[tid] = g.b[RHO0][tid];
+    __syncthreads();
+    {
+      f32x16 acc[1];
+      acc[0] = splat(BS[wave * 32 + r]);
+      wave_mma<1, 32, 33, 1, 1, 33>(acc, Ipool, WS + wave * 32 * 33, lane);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[0][i] = fmaxf(acc[0][i], 0.f);
+      store_tile<129>(Ir1, wave * 32, acc[0], lane);
+    }
+    __syncthreads();
+    // ---- rho.2 (128 -> 64): wave w takes column tile w&1 and half of K; halves are added in LDS
+    load_weight(WS, 129, g.w[RHO2], 64, 128, tid, 256);
+    if (tid < 64) BS[tid] = g.b[RHO2][tid];
+    __syncthreads();
+    {
+      const int jt = wave & 1, kh = wave >> 1;
+      f32x16 acc[1];
+      acc[0] = splat(kh == 0 ? BS[jt * 32 + r] : 0.f);
+      wave_mma<1, 64, 129, 1, 1, 129>(acc, Ir1 + 64 * kh, WS + jt * 32 * 129 + 64 * kh, lane);
+      if (kh == 0) store_tile<65>(Ir2, jt * 32, acc[0], lane);
+      __syncthreads();
+      if (kh == 1) {
+        const int h = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Ir2[drow(i, h) * 65 + jt * 32 + r] += acc[0][i];
+      }
+    }
+    __syncthreads();
+    // ---- heads: [to_mean ; to_logvar] as one [2g][64] weight image
+    zero_img(WS, 32 * 65, tid);
+    __syncthreads();
+    load_weight(WS, 65, g.w[MEAN], gd, 64, tid, 256);
+    load_weight(WS + gd * 65, 65, g.w[LOGVAR], gd, 64, tid, 256);
+    if (tid < 32) BS[tid] = tid < gd ? g.b[MEAN][tid] : (tid < 2 * gd ? g.b[LOGVAR][tid - gd] : 0.f);
+    __syncthreads();
+    if (wave == 0) {
+      f32x16 acc[1];
+      acc[0] = splat(BS[r]);
+      wave_mma<1, 64, 65, 1, 1, 65>(acc, Ir2, WS, lane);
+      store_tile<33>(Iml, 0, acc[0], lane);
+    }
+    __syncthreads();
+    // ---- reparameterisation z = mean + eps * exp(logvar / 2)   (zero-padded to 16 columns)
+    for (int idx = tid; idx < 32 * 16; idx += 256) {
+      const int rr = idx >> 4, j = idx & 15;
+      float zv = 0.f;
+      if (j < gd && row0 + rr < g.B)
+        zv = Iml[rr * 33 + j] + g.eps[(long)(row0 + rr) * gd + j] * expf(0.5f * Iml[rr * 33 + gd + j]);
+      Iz[rr * 17 + j] = zv;
+    }
+    // ---- decoder.0 (g -> 128, ReLU): K padded to 16 with zero weights
+    zero_img(WS, 128 * 17, tid);
+    __syncthreads();
+    load_weight(WS, 17, g.w[DEC0], 128, gd, tid, 256);
+    if (tid < 128) BS[tid] = g.b[DEC0][tid];
+    __syncthreads();
+    {
+      f32x16 acc[1];
+      acc[0] = splat(BS[wave * 32 + r]);
+      wave_mma<1, 16, 17, 1, 1, 17>(acc, Iz, WS + wave * 32 * 17, lane);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[0][i] = fmaxf(acc[0][i], 0.f);
+      store_tile<129>(Id1, wave * 32, acc[0], lane);
+    }
+    __syncthreads();
+    // ---- decoder.2 (128 -> 32): K split over the four waves, partial sums added in LDS in wave order
+    load_weight(WS, 129, g.w[DEC2], 32, 128, tid, 256);
+    if (tid < 32) BS[tid] = g.b[DEC2][tid];
+    __syncthreads();
+    {
+      f32x16 acc[1];
+      acc[0] = splat(wave == 0 ? BS[r] : 0.f);
+      wave_mma<1, 32, 129, 1, 1, 129>(acc, Id1 + 32 * wave, WS + 32 * wave, lane);
+      const int h = lane >> 5;
+      for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            float* p = Id2 + drow(i, h) * 33 + r;
+            *p = w == 0 ? acc[0][i] : *p + acc[0][i];
+          }
+        }
+        __syncthreads();
+      }
+    }
+    // ---- save what the backward pass and the per-car kernel need
+    store_rows(Ih1, 17, g.h1s, 16, row0, g.B, tid);
+    store_rows(Ipool, 33, g.pooled, 32, row0, g.B, tid);
+    store_rows(Ir1, 129, g.r1, 128, row0, g.B, tid);
+    store_rows(Ir2, 65, g.r2, 64, row0, g.B, tid);
+    store_rows(Iml, 33, g.ml, 2 * gd, row0, g.B, tid);
+    store_rows(Iz, 17, g.z, gd, row0, g.B, tid);
+    store_rows(Id1, 129, g.d1, 128, row0, g.B, tid);
+    store_rows(Id2, 33, g.d2, 32, row0, g.B, tid);
+  }
+}
+
+// Column sums of a [32][cols] image, one column per thread (cols <= 128).
+__device__ __forceinline__ float colsum32(const float* img, int ld, int col) {
+  float s = 0.f;
+#pragma unroll 8
+  for (int rr = 0; rr < 32; ++rr) s += img[rr * ld + col];
+  return s;
+}
+
+__global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  float* WS = lds + LN_WS;
+  float* IA = lds + LN_A;      // [32][129]: d1, later r1
+  float* IB = lds + LN_B;      // [32][129]: dd1, later dr1
+  float* IC = lds + LN_C;      // [32][65]: r2
+  float* ID = lds + LN_D;      // [32][65]: dr2
+  float* IE = lds + LN_E;      // [32][33]: dd2, later pooled
+  float* IF = lds + LN_F;      // [32][33]: ml, later dpooled
+  float* IG = lds + LN_G;      // [32][33]: dml
+  float* IH = lds + LN_H;      // [32][33]: z / dz (17-wide), later h1s and t = dpooled*Wphi2
+  const int gd = g.g;
+
+  // weight-gradient tiles owned by this wave, kept across tiles
+  f32x16 aDec2 = splat(0.f), aDec0 = splat(0.f), aHead = splat(0.f), aRho2a = splat(0.f), aRho2b = splat(0.f);
+  f32x16 aRho0 = splat(0.f), aPhi2 = splat(0.f);
+  // bias gradients: thread tid owns column tid of each layer
+  float bDec2 = 0.f, bDec0 = 0.f, bHead = 0.f, bRho2 = 0.f, bRho0 = 0.f, bPhi2 = 0.f;
+  float gPhi0a = 0.f, gPhi0b = 0.f, gPhi0c = 0.f;     // threads 0..15: dW_phi0[k][0], [k][1], db_phi0[k]
+  float klacc = 0.f;
+
+  for (int tile = blockIdx.x; tile < g.tiles; tile += gridDim.x) {
+    const int row0 = tile * 32;
+    __syncthreads();
+    load_rows(IE, 33, g.d_d2, 32, row0, g.B, tid);
+    load_rows(IA, 129, g.d1, 128, row0, g.B, tid);
+    load_weight(WS, 129, g.w[DEC2], 32, 128, tid, 256);
+    __syncthreads();
+    // ---- decoder.2 backward: dW[32][128] += dd2^T d1 (tile `wave`), db, dd1 = (dd2 W) o relu'(d1)
+    {
+      f32x16 acc[1] = {aDec2};
+      wave_mma<1, 32, 1, 33, 129, 1>(acc, IE, IA + 32 * wave, lane);
+      aDec2 = acc[0];
+      if (tid < 32) bDec2 += colsum32(IE, 33, tid);
+      f32x16 d[1];
+      d[0] = splat(0.f);
+      wave_mma<1, 32, 33, 1, 129, 1>(d, IE, WS + 32 * wave, lane);
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        IB[drow(i, h) * 129 + 32 * wave + r] = IA[drow(i, h) * 129 + 32 * wave + r] > 0.f ? d[0][i] : 0.f;
+    }
+    __syncthreads();
+    // ---- decoder.0 backward: dW[128][g] += dd1^T z (row tile `wave`), db, dz = dd1 W
+    zero_img(IH, 32 * 33, tid);
+    zero_img(WS, 128 * 17, tid);
+    __syncthreads();
+    load_rows(IH, 17, g.z, gd, row0, g.B, tid);
+    load_weight(WS, 17, g.w[DEC0], 128, gd, tid, 256);
+    load_rows(IF, 33, g.ml, 2 * gd, row0, g.B, tid);
+    __syncthreads();
+    {
+      f32x16 acc[1] = {aDec0};
+      wave_mma<1, 32, 1, 129, 17, 1>(acc, IB + 32 * wave, IH, lane);
+      aDec0 = acc[0];
+      if (tid < 128) bDec0 += colsum32(IB, 129, tid);
+    }
+    __syncthreads();      // z image is consumed; dz overwrites it below
+    if (wave == 0) {
+      // dz[32][g] = dd1[32][128] * W_dec0[128][g]   (columns >= g read zero weights)
+      f32x16 d[1];
+      d[0] = splat(0.f);
+      wave_mma<1, 128, 129, 1, 17, 1>(d, IB, WS, lane);
+      store_tile<33>(IG, 0, d[0], lane);       // dz parked in IG columns 0..g-1
+    }
+    __syncthreads();
+    // ---- latent gradient (KL + reparameterisation): dml = [dz + mean | dz*eps*0.5*std + 0.5*(exp(lv)-1) | 0...]
+    for (int idx = tid; idx < 32 * 32; idx += 256) {
+      const int rr = idx >> 5, c = idx & 31;
+      float outv = 0.f;
+      if (c < 2 * gd && row0 + rr < g.B) {
+        const int j = c < gd ? c : c - gd;
+        const float mean = IF[rr * 33 + j], lv = IF[rr * 33 + gd + j];
+        const float dz = IG[rr * 33 + j];
+        if (c < gd) {
+          outv = dz + mean;
+          klacc += -0.5f * (1.f + lv - mean * mean - expf(lv));
+        } else {
+          outv = dz * g.eps[(long)(row0 + rr) * gd + j] * 0.5f * expf(0.5f * lv) + 0.5f * (expf(lv) - 1.f);
+        }
+      }
+      IH[rr * 33 + c] = outv;
+    }
+    __syncthreads();
+    // dml now lives in IH columns 0..2g-1, zeros beyond
+    // ---- heads backward: dW[2g][64] += dml^T r2 (column tile wave&1, waves 0,1), db, dr2 = dml W (waves 2,3)
+    load_rows(IC, 65, g.r2, 64, row0, g.B, tid);
+    zero_img(WS, 32 * 65, tid);
+    __syncthreads();
+    load_weight(WS, 65, g.w[MEAN], gd, 64, tid, 256);
+    load_weight(WS + gd * 65, 65, g.w[LOGVAR], gd, 64, tid, 256);
+    __syncthreads();
+    if (wave < 2) {
+      f32x16 acc[1] = {aHead};
+      wave_mma<1, 32, 1, 33, 65, 1>(acc, IH, IC + 32 * wave, lane);
+      aHead = acc[0];
+    } else {
+      f32x16 d[1];
+      d[0] = splat(0.f);
+      wave_mma<1, 32, 33, 1, 65, 1>(d, IH, WS + 32 * (wave - 2), lane);
+      store_tile<65>(ID, 32 * (wave - 2), d[0], lane);
+    }
+    if (tid < 32) bHead += colsum32(IH, 33, tid);
+    __syncthreads();
+    // ---- rho.2 backward: dW[64][128] += dr2^T r1 (8 tiles, two per wave), db, dr1 = (dr2 W) o relu'(r1)
+    load_rows(IA, 129, g.r1, 128, row0, g.B, tid);
+    load_weight(WS, 129, g.w[RHO2], 64, 128, tid, 256);
+    __syncthreads();
+    {
+      const int it = wave >> 1, jt0 = (wave & 1) * 2;
+      f32x16 acc[2] = {aRho2a, aRho2b};
+      wave_mma<2, 32, 1, 65, 129, 1>(acc, ID + 32 * it, IA + 32 * jt0, lane);
+      aRho2a = acc[0];
+      aRho2b = acc[1];
+      if (tid < 64) bRho2 += colsum32(ID, 65, tid);
+      f32x16 d[1];
+      d[0] = splat(0.f);
+      wave_mma<1, 64, 65, 1, 129, 1>(d, ID, WS + 32 * wave, lane);
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        IB[drow(i, h) * 129 + 32 * wave + r] = IA[drow(i, h) * 129 + 32 * wave + r] > 0.f ? d[0][i] : 0.f;
+    }
+    __syncthreads();
+    // ---- rho.0 backward: dW[128][32] += dr1^T pooled (row tile `wave`), db, dpooled = dr1 W
+    load_rows(IE, 33, g.pooled, 32, row0, g.B, tid);
+    load_weight(WS, 33, g.w[RHO0], 128, 32, tid, 256);
+    __syncthreads();
+    {
+      f32x16 acc[1] = {aRho0};
+      wave_mma<1, 32, 1, 129, 33, 1>(acc, IB + 32 * wave, IE, lane);
+      aRho0 = acc[0];
+      if (tid < 128) bRho0 += colsum32(IB, 129, tid);
+      // dpooled: K = 128 split over the waves, partial sums added in LDS in wave order
+      f32x16 d[1];
+      d[0] = splat(0.f);
+      wave_mma<1, 32, 129, 1, 33, 1>(d, IB + 32 * wave, WS + 32 * wave * 33, lane);
+      for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            float* p = IF + drow(i, h) * 33 + r;
+            *p = w == 0 ? d[0][i] : *p + d[0][i];
+          }
+        }
+        __syncthreads();
+      }
+    }
+    // ---- phi.2 backward on the pooled hidden: dW[32][16] += dpooled^T h1s, db = N * colsum(dpooled),
+    //      t = dpooled W_phi2 (gradient at every car's hidden layer of that lane, before its ReLU mask)
+    zero_img(IH, 32 * 33, tid);
+    __syncthreads();
+    load_rows(IH, 33, g.h1s, 16, row0, g.B, tid);
+    load_weight(WS, 17, g.w[PHI2], 32, 16, tid, 256);
+    __syncthreads();
+    if (wave == 0) {
+      f32x16 acc[1] = {aPhi2};
+      wave_mma<1, 32, 1, 33, 33, 1>(acc, IF, IH, lane);
+      aPhi2 = acc[0];
+    }
+    if (tid < 32) bPhi2 += (float)g.N * colsum32(IF, 33, tid);
+    if (wave == 1) {
+      f32x16 d[1];
+      d[0] = splat(0.f);
+      wave_mma<1, 32, 33, 1, 17, 1>(d, IF, WS, lane);    // columns >= 16 read past the [32][17] image: discarded below
+      if (r < 16) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) IG[drow(i, h) * 33 + r] = d[0][i];
+      }
+    }
+    __syncthreads();
+    // ---- phi.0 backward: per (lane, hidden unit) walk the cars again, apply the ReLU mask
+    {
+      float* red = IC;       // [32][3*16] partials, r2 image is free now
+      for (int idx = tid; idx < 32 * 16; idx += 256) {
+        const int rr = idx >> 4, k = idx & 15;
+        const int b = row0 + rr;
+        float a0 = 0.f, a1 = 0.f, c = 0.f;
+        if (b < g.B) {
+          const float wa = g.w[PHI0][2 * k], wb = g.w[PHI0][2 * k + 1], bb = g.b[PHI0][k];
+          const float* x = g.data + (long)b * g.N * 2;
+          for (int n = 0; n < g.N; ++n) {
+            const float x0 = x[2 * n], x1 = x[2 * n + 1];
+            if (wa * x0 + wb * x1 + bb > 0.f) { a0 += x0; a1 += x1; c += 1.f; }
+          }
+        }
+        const float t = IG[rr * 33 + k];
+        red[rr * 49 + k] = t * a0;
+        red[rr * 49 + 16 + k] = t * a1;
+        red[rr * 49 + 32 + k] = t * c;
+      }
+      __syncthreads();
+      if (tid < 48) {
+        float s = 0.f;
+        for (int rr = 0; rr < 32; ++rr) s += red[rr * 49 + tid];
+        if (tid < 16) gPhi0a += s; else if (tid < 32) gPhi0b += s; else gPhi0c += s;
+      }
+    }
+  }
+
+  // ---- write this workgroup's slab
+  float* slab = g.slab + (long)blockIdx.x * g.off.total;
+  auto put_tile = [&](long base, int ld, int row_lim, int col0, int col_lim, const f32x16& t) {
+    const int col = col0 + r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = drow(i, h);
+      if (row < row_lim && col < col_lim) slab[base + (long)row * ld + col] = t[i];
+    }
+  };
+  put_tile(g.off.w[DEC2], 128, 32, 32 * wave, 128, aDec2);
+  put_tile(g.off.w[DEC0] + (long)32 * wave * gd, gd, 32, 0, gd, aDec0);
+  if (wave < 2) {
+    // rows 0..g-1 -> to_mean, rows g..2g-1 -> to_logvar; columns 32*wave..
+    const int col = 32 * wave + r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = drow(i, h);
+      if (row < gd) slab[g.off.w[MEAN] + (long)row * 64 + col] = aHead[i];
+      else if (row < 2 * gd) slab[g.off.w[LOGVAR] + (long)(row - gd) * 64 + col] = aHead[i];
+    }
+  }
+  {
+    const int it = wave >> 1, jt0 = (wave & 1) * 2;
+    put_tile(g.off.w[RHO2] + (long)32 * it * 128, 128, 32, 32 * jt0, 128, aRho2a);
+    put_tile(g.off.w[RHO2] + (long)32 * it * 128, 128, 32, 32 * (jt0 + 1), 128, aRho2b);
+  }
+  put_tile(g.off.w[RHO0] + (long)32 * wave * 32, 32, 32, 0, 32, aRho0);
+  if (wave == 0) put_tile(g.off.w[PHI2], 16, 32, 0, 16, aPhi2);
+  if (tid < 32) {
+    slab[g.off.b[DEC2] + tid] = bDec2;
+    slab[g.off.b[PHI2] + tid] = bPhi2;
+    if (tid < gd) slab[g.off.b[MEAN] + tid] = bHead;
+    else if (tid < 2 * gd) slab[g.off.b[LOGVAR] + tid - gd] = bHead;
+  }
+  if (tid < 128) {
+    slab[g.off.b[DEC0] + tid] = bDec0;
+    slab[g.off.b[RHO0] + tid] = bRho0;
+  }
+  if (tid < 64) slab[g.off.b[RHO2] + tid] = bRho2;
+  if (tid < 16) {
+    slab[g.off.w[PHI0] + 2 * tid] = gPhi0a;
+  } else if (tid < 32) {
+    slab[g.off.w[PHI0] + 2 * (tid - 16) + 1] = gPhi0b;
+  } else if (tid < 48) {
+    slab[g.off.b[PHI0] + tid - 32] = gPhi0c;
+  }
+  // KL partial of this workgroup
+  klacc = wave_sum(klacc);
+  __shared__ float klred[4];
+  if (lane == 0) klred[wave] = klacc;
+  __syncthreads();
+  if (tid == 0) g.kl_part[blockIdx.x] = klred[0] + klred[1] + klred[2] + klred[3];
+}
+
+// grads[i] = sum over slabs (fixed order); loss = sum of the partial losses
+__global__ __launch_bounds__(256) void vae_reduce_grads_kernel(const float* __restrict__ slab, long total, int n_car, int n_lane,
+                                                               long car_lo, long car_hi, float* grads,
+                                                               const float* __restrict__ loss_part, const float* __restrict__ kl_part,
+                                                               float* loss) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) {
+    // per-car layers (loc, func.*) occupy [car_lo, car_hi) and come from the per-car kernel's slabs
+    const int n = (i >= car_lo && i < car_hi) ? n_car : n_lane;
+    float s = 0.f;
+    for (int k = 0; k < n; ++k) s += slab[(long)k * total + i];
+    grads[i] = s;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    float s = 0.f;
+    for (int k = threadIdx.x; k < n_car; k += 64) s += loss_part[k];
+    for (int k = threadIdx.x; k < n_lane; k += 64) s += kl_part[k];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) *loss = s;
+  }
+}
+
+struct Ws {
+  float *h1s, *pooled, *r1, *r2, *ml, *z, *d1, *d2, *d_d2, *loss_part, *kl_part, *slab;
+  long total;
+};
+
+static long a64(long n) { return (n + 63) & ~63L; }
+
+static int grid_car(long rows) {
+  const long tiles = (rows + 31) / 32;
+  long gsz = (tiles + 3) / 4;
+  if (gsz > 256) gsz = 256;
+  return (int)(gsz < 1 ? 1 : gsz);
+}
+static int grid_lane(int B) {
+  long tiles = (B + 31) / 32;
+  if (tiles > 256) tiles = 256;
+  return (int)(tiles < 1 ? 1 : tiles);
+}
+
+static Ws carve(float* ws, int B, int N, int g, long n_flat) {
+  Ws w;
+  long off = 0;
+  auto take = [&](long n) { float* p = ws ? ws + off : nullptr; off += a64(n); return p; };
+  w.h1s = take((long)B * 16);
+  w.pooled = take((long)B * 32);
+  w.r1 = take((long)B * 128);
+  w.r2 = take((long)B * 64);
+  w.ml = take((long)B * 2 * g);
+  w.z = take((long)B * g);
+  w.d1 = take((long)B * 128);
+  w.d2 = take((long)B * 32);
+  w.d_d2 = take((long)B * 32);
+  w.loss_part = take(256);
+  w.kl_part = take(256);
+  const int ns = grid_car((long)B * N) > grid_lane(B) ? grid_car((long)B * N) : grid_lane(B);
+  w.slab = take((long)ns * n_flat);
+  w.total = off;
+  return w;
+}
+
+}  // namespace vf
+}  // namespace hhrl
+
+using namespace hhrl;
+using namespace hhrl::vf;
+
+extern "C" {
+
+long hhrl_vae_workspace_floats(int B, int N, int g, long n_flat) {
+  if (B <= 0 || N <= 0 || g <= 0 || n_flat <= 0) return 0;
+  return carve(nullptr, B, N, g, n_flat).total;
+}
+
+int hhrl_vae_train_step(const float* params, float* grads, const long* offsets, long n_flat, const float* data,
+                        const float* eps, int B, int N, int g, float recon_scale, float* loss, float* ws,
+                        void* stream) {
+  HHRL_REQUIRE(params && grads && offsets && data && eps && loss && ws, "vae_train_step: null pointer");
+  HHRL_REQUIRE(B > 0 && N > 0, "vae_train_step: bad shape B=%d N=%d", B, N);
+  HHRL_REQUIRE(g == 2 || g == 4 || g == 8 || g == 16, "vae_train_step: latent size %d not in {2,4,8,16}", g);
+  HHRL_REQUIRE((long)B * N < (1L << 31) - 64, "vae_train_step: B*N too large");
+  static const long numel_w[NLAYER] = {32, 512, 4096, 8192, -64, -64, -128, 4096, 32, 8192, 4096, 32};
+  static const long numel_b[NLAYER] = {16, 32, 128, 64, -1, -1, 128, 32, 32, 128, 32, 1};
+  Offsets off;
+  for (int l = 0; l < NLAYER; ++l) {
+    off.w[l] = offsets[2 * l];
+    off.b[l] = offsets[2 * l + 1];
+    const long nw = numel_w[l] < 0 ? -numel_w[l] * g : numel_w[l];
+    const long nb = numel_b[l] < 0 ? g : numel_b[l];
+    HHRL_REQUIRE(off.w[l] >= 0 && off.w[l] + nw <= n_flat && off.b[l] >= 0 && off.b[l] + nb <= n_flat,
+                 "vae_train_step: offsets[%d] outside the flat buffer", l);
+  }
+  off.total = n_flat;
+  // per-car layers must be contiguous at the end of the layout (loc, func.0, func.2, func.4)
+  const long car_lo = off.w[LOC], car_hi = off.b[FUNC4] + 1;
+  HHRL_REQUIRE(car_lo > off.b[DEC2] && off.w[FUNC0] > car_lo && off.b[FUNC4] > off.w[FUNC0],
+               "vae_train_step: unexpected parameter order");
+  hipStream_t st = as_stream(stream);
+  Ws w = carve(ws, B, N, g, n_flat);
+  const long rows = (long)B * N;
+  const int ncar = grid_car(rows), nlane = grid_lane(B);
+
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(vae_car_fwd_bwd_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, CAR_LDS_FLOATS * 4);
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(vae_lane_forward_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS_FLOATS * 4);
+    hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(vae_lane_backward_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS_FLOATS * 4);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess)
+      return fail(HHRL_ERR_HIP, "vae_train_step: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    attr_done = true;
+  }
+
+  LaneArgs la;
+  la.data = data;
+  la.eps = eps;
+  for (int l = 0; l < NLAYER; ++l) {
+    la.w[l] = params + off.w[l];
+    la.b[l] = params + off.b[l];
+  }
+  la.h1s = w.h1s; la.pooled = w.pooled; la.r1 = w.r1; la.r2 = w.r2; la.ml = w.ml; la.z = w.z; la.d1 = w.d1; la.d2 = w.d2;
+  la.d_d2 = w.d_d2;
+  la.slab = w.slab;
+  la.kl_part = w.kl_part;
+  la.off = off;
+  la.B = B; la.N = N; la.g = g; la.tiles = (B + 31) / 32;
+
+  const double lane_macs = 16.0 * 2 * N + 512 + 4096 + 8192 + 128.0 * g + 128.0 * g + 4096;
+  {
+    ProfScope ps("vae_lane_forward_kernel", st, 2.0 * lane_macs * B, 4.0 * B * (2.0 * N + g + 16 + 32 + 128 + 64 + 3 * g + 128 + 32));
+    hipLaunchKernelGGL(vae_lane_forward_kernel, dim3(nlane), dim3(256), LN_LDS_FLOATS * 4, st, la);
+    HHRL_TRY(launch_status("vae_lane_forward_kernel"));
+  }
+  if (hipMemsetAsync(w.d_d2, 0, sizeof(float) * (size_t)B * 32, st) != hipSuccess)
+    return fail(HHRL_ERR_HIP, "vae_train_step: hipMemsetAsync failed");
+
+  CarArgs ca;
+  ca.data = data;
+  ca.d2 = w.d2;
+  ca.wloc = la.w[LOC]; ca.bloc = la.b[LOC];
+  ca.w0 = la.w[FUNC0]; ca.b0 = la.b[FUNC0];
+  ca.w2 = la.w[FUNC2]; ca.b2 = la.b[FUNC2];
+  ca.w4 = la.w[FUNC4]; ca.b4 = la.b[FUNC4];
+  ca.d_d2 = w.d_d2;
+  ca.slab = w.slab;
+  ca.loss_part = w.loss_part;
+  ca.off = off;
+  ca.rows = rows;
+  ca.N = N;
+  ca.tiles = (int)((rows + 31) / 32);
+  ca.recon_scale = recon_scale;
+  {
+    // forward + input-gradient + weight-gradient products of loc/func.0/func.2/func.4: 3 * 2 * 12352 flop per car
+    ProfScope ps("vae_car_fwd_bwd_kernel", st, 6.0 * (8192 + 4096 + 32 + 32) * rows, 4.0 * (2.0 * rows + 64.0 * B));
+    hipLaunchKernelGGL(vae_car_fwd_bwd_kernel, dim3(ncar), dim3(256), CAR_LDS_FLOATS * 4, st, ca);
+    HHRL_TRY(launch_status("vae_car_fwd_bwd_kernel"));
+  }
+  {
+    ProfScope ps("vae_lane_backward_kernel", st, 4.0 * lane_macs * B, 4.0 * B * (2.0 * N + g + 32 + 16 + 32 + 128 + 64 + 3 * g + 128));
+    hipLaunchKernelGGL(vae_lane_backward_kernel, dim3(nlane), dim3(256), LN_LDS_FLOATS * 4, st, la);
+    HHRL_TRY(launch_status("vae_lane_backward_kernel"));
+  }
+  {
+    ProfScope ps("vae_reduce_grads_kernel", st, 0.0, 4.0 * n_flat * (1.0 + 0.5 * (ncar + nlane)));
+    hipLaunchKernelGGL(vae_reduce_grads_kernel, dim3(ceil_div(n_flat, 256)), dim3(256), 0, st, w.slab, n_flat, ncar, nlane,
+                       car_lo, car_hi, grads, w.loss_part, w.kl_part, loss);
+    HHRL_TRY(launch_status("vae_reduce_grads_kernel"));
+  }
+  return HHRL_OK;
+}
+
+}  // extern "C"

@@ -86,7 +86,7 @@ class Encoder:
     """
 
     def __init__(self, car_info_dim: int, goal_dim: int, device: Optional[str] = None, seed: Optional[int] = None,
-                 group=None):
+                 group=None, fused: bool = True):
         if car_info_dim != 2:
             raise ValueError("the lane state is (location, speed): car_info_dim must be 2 (algorithm.py:94-95)")
         if not torch.cuda.is_available():
@@ -109,6 +109,12 @@ class Encoder:
         self.func0, self.func2 = L("decoder.func.0", ACT_RELU), L("decoder.func.2", ACT_RELU)
         self.func4 = L("decoder.func.4", ACT_SIGMOID)
         self._work: Dict[Tuple[int, int], _Work] = {}
+        # fused = True: the four-launch fused training step; False: one launch per layer
+        # (same arithmetic, kept as a cross-check and for latent sizes the fused kernels do not cover)
+        self.fused = bool(fused) and self.goal_dim in (2, 4, 8, 16)
+        self._fused_ws: Dict[Tuple[int, int], torch.Tensor] = {}
+        import ctypes
+        self._offsets = (ctypes.c_long * 24)(*[self.layout.offsets[n] for n in self.layout.names])
         self._loss = ops.dev_zeros(1, device=self.device)
         self._rng = torch.Generator(device=self.device)
         self._rng.manual_seed(3407)
@@ -176,10 +182,22 @@ class Encoder:
             eps = torch.as_tensor(eps, dtype=torch.float32).to(self.device).contiguous()
             if tuple(eps.shape) != (B, g):
                 raise ValueError("eps must be [%d, %d], got %s" % (B, g, tuple(eps.shape)))
-        w = self._ws(B, N)
-        M = w.M
         st = _lib.stream_ptr()
         lib = self._lib
+        if self.fused:
+            ws = self._fused_ws.get((B, N))
+            if ws is None:
+                if len(self._fused_ws) > 64:
+                    self._fused_ws.clear()
+                n = lib.hhrl_vae_workspace_floats(B, N, g, self.layout.size)
+                ws = self._fused_ws[(B, N)] = ops.dev_zeros(n, device=self.device)
+            scale = 1.0 / float(recon_count if recon_count is not None else B * N)
+            check(lib.hhrl_vae_train_step(self.params.base_ptr, self.opt.g.base_ptr, self._offsets, self.layout.size,
+                                          P(x), P(eps), B, N, g, scale, P(self._loss), P(ws), st))
+            self._keep = (x, eps)
+            return self._loss[0]
+        w = self._ws(B, N)
+        M = w.M
         self.opt.zero_grad()                                            # algorithm.py:98
         self._loss.zero_()
         self._encode_fwd(x, w)                                          # :99

@@ -93,6 +93,25 @@ int hhrl_vae_elbo(const float* decoded, const float* data, const float* ml, floa
 int hhrl_vae_latent_grad(const float* dz, const float* ml, const float* eps, float* d_ml,
                          int B, int g, void* stream);
 
+/* One whole training step's forward + ELBO + backward, fused
+ * (Encoder.learn minus the optimiser, algorithm.py:94-105):
+ *   params/grads : flat fp32 buffers of n_flat floats holding the 24 tensors of
+ *                  Encoder.parameters() at offsets[0..23] (HOST array, element
+ *                  offsets, order weight,bias per layer: phi.0 phi.2 rho.0 rho.2
+ *                  to_mean to_logvar decoder.0 decoder.2 loc func.0 func.2 func.4);
+ *   data [B*N,2] (loc, v), eps [B,g]; g in {2,4,8,16};
+ *   grads is OVERWRITTEN with dL/dparams (fixed-order reduction: the same
+ *   inputs give the same bits), *loss with recon_scale*sum(err^2) + KL;
+ *   ws: hhrl_vae_workspace_floats(B,N,g,n_flat) floats, zero-filled once by the
+ *   caller and then left to the library.
+ * Four launches: per-lane forward, per-car forward+backward, per-lane
+ * backward, slab reduction; all matrix products on fp32 MFMA with LDS-resident
+ * weights. */
+long hhrl_vae_workspace_floats(int B, int N, int g, long n_flat);
+int hhrl_vae_train_step(const float* params, float* grads, const long* offsets, long n_flat,
+                        const float* data, const float* eps, int B, int N, int g,
+                        float recon_scale, float* loss, float* ws, void* stream);
+
 /* --------------------------------------------------------------------- TD3
  * Target-policy smoothing (algorithm.py:295-296, 494-497, 786-791, 1135-1136, 1330-1331):
  *   out = clamp(pi + clamp(0.2*eps, -0.5, 0.5), -1, 1);  eps ~ N(0,1) from the caller. */
