@@ -296,11 +296,13 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
     // ---- latent gradient: d_d2[lane] += sum over that lane's cars of dcat[:, 0:32]
     store_tile<33>(half, 0, dcat[0], lane);
     wave_sync();
-    {
-      int prev = lidx[16 * h];
+    if (h == 0) {
+      // one partial sum per (traffic lane, tile): lanes of up to 32 cars receive at most two
+      // addends, so the atomic result does not depend on arrival order
+      int prev = lidx[0];
       float s = 0.f;
 #pragma unroll 4
-      for (int rr = 16 * h; rr < 16 * h + 16; ++rr) {
+      for (int rr = 0; rr < 32; ++rr) {
         const int b = lidx[rr];
         if (b != prev) {
           if (prev >= 0) unsafeAtomicAdd(&g.d_d2[(long)prev * 32 + r], s);
@@ -834,25 +836,41 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
   if (tid == 0) g.kl_part[blockIdx.x] = klred[0] + klred[1] + klred[2] + klred[3];
 }
 
-// grads[i] = sum over slabs (fixed order); loss = sum of the partial losses
+// grads[i] = sum over slabs, in a fixed order: the same inputs give the same bits.
+// A workgroup owns 64 consecutive parameters; its four waves each sum a quarter of the
+// slabs (four independent running sums keep loads in flight), LDS combines the quarters.
 __global__ __launch_bounds__(256) void vae_reduce_grads_kernel(const float* __restrict__ slab, long total, int n_car, int n_lane,
                                                                long car_lo, long car_hi, float* grads,
                                                                const float* __restrict__ loss_part, const float* __restrict__ kl_part,
                                                                float* loss) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float red[4][64];
+  const int p = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + p;
+  float s = 0.f;
   if (i < total) {
     // per-car layers (loc, func.*) occupy [car_lo, car_hi) and come from the per-car kernel's slabs
     const int n = (i >= car_lo && i < car_hi) ? n_car : n_lane;
-    float s = 0.f;
-    for (int k = 0; k < n; ++k) s += slab[(long)k * total + i];
-    grads[i] = s;
+    const float* col = slab + i;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = q;
+    for (; k + 12 < n; k += 16) {
+      s0 += col[(long)k * total];
+      s1 += col[(long)(k + 4) * total];
+      s2 += col[(long)(k + 8) * total];
+      s3 += col[(long)(k + 12) * total];
+    }
+    for (; k < n; k += 4) s0 += col[(long)k * total];
+    s = (s0 + s1) + (s2 + s3);
   }
+  red[q][p] = s;
+  __syncthreads();
+  if (q == 0 && i < total) grads[i] = (red[0][p] + red[1][p]) + (red[2][p] + red[3][p]);
   if (blockIdx.x == 0 && threadIdx.x < 64) {
-    float s = 0.f;
-    for (int k = threadIdx.x; k < n_car; k += 64) s += loss_part[k];
-    for (int k = threadIdx.x; k < n_lane; k += 64) s += kl_part[k];
-    s = wave_sum(s);
-    if (threadIdx.x == 0) *loss = s;
+    float t = 0.f;
+    for (int k = threadIdx.x; k < n_car; k += 64) t += loss_part[k];
+    for (int k = threadIdx.x; k < n_lane; k += 64) t += kl_part[k];
+    t = wave_sum(t);
+    if (threadIdx.x == 0) *loss = t;
   }
 }
 
@@ -1001,7 +1019,7 @@ int hhrl_vae_train_step(const float* params, float* grads, const long* offsets, 
   }
   {
     ProfScope ps("vae_reduce_grads_kernel", st, 0.0, 4.0 * n_flat * (1.0 + 0.5 * (ncar + nlane)));
-    hipLaunchKernelGGL(vae_reduce_grads_kernel, dim3(ceil_div(n_flat, 256)), dim3(256), 0, st, w.slab, n_flat, ncar, nlane,
+    hipLaunchKernelGGL(vae_reduce_grads_kernel, dim3(ceil_div(n_flat, 64)), dim3(256), 0, st, w.slab, n_flat, ncar, nlane,
                        car_lo, car_hi, grads, w.loss_part, w.kl_part, loss);
     HHRL_TRY(launch_status("vae_reduce_grads_kernel"));
   }

