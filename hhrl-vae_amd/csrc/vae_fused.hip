@@ -75,11 +75,39 @@ __device__ __forceinline__ void store_tile(float* img, int col0, const f32x16& t
   for (int i = 0; i < 16; ++i) img[drow(i, h) * LD + col0 + r] = t[i];
 }
 
-// Copy a [rows][cols] row-major global matrix into an LDS image with row stride LD.
+// Copy a [rows][cols] row-major global matrix into an LDS image with row stride ld (generic, scalar).
 __device__ __forceinline__ void load_weight(float* img, int ld, const float* __restrict__ w, int rows, int cols, int tid, int nthreads) {
   for (int idx = tid; idx < rows * cols; idx += nthreads) {
     const int r = idx / cols, c = idx - r * cols;
     img[r * ld + c] = w[idx];
+  }
+}
+
+// Same for compile-time shapes with COLS % 4 == 0 and a 16-byte aligned source: 16-byte loads,
+// four of them issued back to back per thread so that their latencies overlap.
+template <int ROWS, int COLS>
+__device__ __forceinline__ void load_weight_v4(float* img, int ld, const float* __restrict__ w, int tid) {
+  static_assert(COLS % 4 == 0, "row length must be a multiple of 4");
+  constexpr int TOTAL4 = ROWS * COLS / 4;
+  const float4* w4 = reinterpret_cast<const float4*>(w);
+#pragma unroll 1
+  for (int base = 0; base < TOTAL4; base += 4 * 256) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i4 = base + u * 256 + tid;
+      if (i4 < TOTAL4) v[u] = w4[i4];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i4 = base + u * 256 + tid;
+      if (i4 < TOTAL4) {
+        const int idx = i4 * 4;
+        const int r = idx / COLS, c = idx % COLS;
+        float* p = img + r * ld + c;
+        p[0] = v[u].x; p[1] = v[u].y; p[2] = v[u].z; p[3] = v[u].w;
+      }
+    }
   }
 }
 
@@ -121,8 +149,8 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
   float* wlocs = w4s + 32;
   float* blocs = wlocs + 32;
   float* b4s = blocs + 32;
-  load_weight(W0s, 65, g.w0, 128, 64, tid, 256);
-  load_weight(W2s, 129, g.w2, 32, 128, tid, 256);
+  load_weight_v4<128, 64>(W0s, 65, g.w0, tid);
+  load_weight_v4<32, 128>(W2s, 129, g.w2, tid);
   if (tid < 128) b0s[tid] = g.b0[tid];
   if (tid < 32) {
     b2s[tid] = g.b2[tid];
@@ -387,275 +415,298 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
 }
 
 // ===================================================================== per-lane kernels
+// One workgroup owns tiles of 32 traffic lanes.  ALL per-lane weights are
+// copied into LDS once per workgroup; every activation of the chain lives in an
+// LDS image, so the chain touches global memory only for its inputs (car
+// states, eps, the latent gradient) and outputs.  The backward kernel
+// recomputes the forward chain in LDS instead of reloading saved activations,
+// and overwrites activations with their gradients in place.
 struct LaneArgs {
   const float* data;   // [B*N][2]
   const float* eps;    // [B][g]
   const float* w[NLAYER];
   const float* b[NLAYER];
-  // saved activations, [B][.]
-  float *h1s, *pooled, *r1, *r2, *ml, *z, *d1, *d2;
-  const float* d_d2;   // backward input
+  float* d2;           // [B][32] forward output
+  const float* d_d2;   // [B][32] backward input
   float* slab;
   float* kl_part;      // [gridDim.x]
   Offsets off;
   int B, N, g, tiles;
 };
 
-// image slots (floats) shared by the four waves of a workgroup
-constexpr int LN_WS = 0;                       // weight slot: up to [64][129]
-constexpr int LN_BIAS = LN_WS + 64 * 129;      // 128
-constexpr int LN_A = LN_BIAS + 128;            // [32][129]
-constexpr int LN_B = LN_A + 32 * 129;          // [32][129]
-constexpr int LN_C = LN_B + 32 * 129;          // [32][65]
-constexpr int LN_D = LN_C + 32 * 65;           // [32][65]
-constexpr int LN_E = LN_D + 32 * 65;           // [32][33]
-constexpr int LN_F = LN_E + 32 * 33;           // [32][33]
-constexpr int LN_G = LN_F + 32 * 33;           // [32][33]
-constexpr int LN_H = LN_G + 32 * 33;           // [32][33]
-constexpr int LN_LDS_FLOATS = LN_H + 32 * 33;
+// LDS map (floats)
+constexpr int LW_PHI2 = 0;                        // [32][17]
+constexpr int LW_RHO0 = LW_PHI2 + 32 * 17;        // [128][33]
+constexpr int LW_RHO2 = LW_RHO0 + 128 * 33;       // [64][129]
+constexpr int LW_HEAD = LW_RHO2 + 64 * 129;       // [32][65]   rows 0..g-1 to_mean, g..2g-1 to_logvar, rest zero
+constexpr int LW_DEC0 = LW_HEAD + 32 * 65;        // [128][17]  columns >= g zero
+constexpr int LW_DEC2 = LW_DEC0 + 128 * 17;       // [32][129]
+constexpr int LW_BIAS = LW_DEC2 + 32 * 129;       // phi2[32] rho0[128] rho2[64] head[32] dec0[128] dec2[32]
+constexpr int LB_PHI2 = 0, LB_RHO0 = 32, LB_RHO2 = 160, LB_HEAD = 224, LB_DEC0 = 256, LB_DEC2 = 384;
+constexpr int LI_H1 = LW_BIAS + 416;              // [32][33]  summed hidden of phi (16 columns used)
+constexpr int LI_POOL = LI_H1 + 32 * 33;          // [32][33]
+constexpr int LI_R1 = LI_POOL + 32 * 33;          // [32][129]
+constexpr int LI_R2 = LI_R1 + 32 * 129;           // [32][65]
+constexpr int LI_ML = LI_R2 + 32 * 65;            // [32][33]  mean | logvar
+constexpr int LI_Z = LI_ML + 32 * 33;             // [32][17]  (in a 33-wide slot)
+constexpr int LI_D1 = LI_Z + 32 * 33;             // [32][129]; doubles as staging for the tile's car states
+constexpr int LI_D2 = LI_D1 + 32 * 129;           // [32][33]
+constexpr int LI_DML = LI_D2 + 32 * 33;           // [32][33]
+constexpr int LI_TMP = LI_DML + 32 * 33;          // [32][33]
+constexpr int LN_LDS_FLOATS = LI_TMP + 32 * 33;
+static_assert(LN_LDS_FLOATS * 4 <= 163840 - 64, "per-lane kernels must fit the 160 KiB LDS");
+constexpr int STAGE_MAX_CARS = 64;                // 32 lanes x 64 cars x 2 floats fit the d1 slot
 
-// Copy rows [row0, row0+32) of a [B][cols] global matrix into an image (zeros beyond B).
-__device__ __forceinline__ void load_rows(float* img, int ld, const float* __restrict__ src, int cols, int row0, int B, int tid) {
-  for (int idx = tid; idx < 32 * cols; idx += 256) {
-    const int rr = idx / cols, c = idx - rr * cols;
-    img[rr * ld + c] = (row0 + rr < B) ? src[(long)(row0 + rr) * cols + c] : 0.f;
+// rows [row0, row0+32) of a [B][32] global matrix <-> a [32][33] image (zeros beyond B)
+__device__ __forceinline__ void load_rows32(float* img, const float* __restrict__ src, int row0, int B, int tid) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int idx = u * 256 + tid, rr = idx >> 5, c = idx & 31;
+    img[rr * 33 + c] = (row0 + rr < B) ? src[(long)(row0 + rr) * 32 + c] : 0.f;
   }
 }
-__device__ __forceinline__ void store_rows(const float* img, int ld, float* dst, int cols, int row0, int B, int tid) {
-  for (int idx = tid; idx < 32 * cols; idx += 256) {
-    const int rr = idx / cols, c = idx - rr * cols;
-    if (row0 + rr < B) dst[(long)(row0 + rr) * cols + c] = img[rr * ld + c];
+__device__ __forceinline__ void store_rows32(const float* img, float* dst, int row0, int B, int tid) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int idx = u * 256 + tid, rr = idx >> 5, c = idx & 31;
+    if (row0 + rr < B) dst[(long)(row0 + rr) * 32 + c] = img[rr * 33 + c];
   }
 }
-__device__ __forceinline__ void zero_img(float* img, int n, int tid) {
-  for (int idx = tid; idx < n; idx += 256) img[idx] = 0.f;
-}
-
-__global__ __launch_bounds__(256, 1) void vae_lane_forward_kernel(LaneArgs g) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31;
-  float* WS = lds + LN_WS;
-  float* BS = lds + LN_BIAS;
-  float* Ir1 = lds + LN_A;     // [32][129]
-  float* Id1 = lds + LN_B;     // [32][129]
-  float* Ir2 = lds + LN_C;     // [32][65]
-  float* Ih1 = lds + LN_D;     // [32][17] inside a 65-wide slot
-  float* Ipool = lds + LN_E;   // [32][33]
-  float* Iml = lds + LN_F;     // [32][33]
-  float* Iz = lds + LN_G;      // [32][17]
-  float* Id2 = lds + LN_H;     // [32][33]
-  const int gd = g.g;
-
-  for (int tile = blockIdx.x; tile < g.tiles; tile += gridDim.x) {
-    const int row0 = tile * 32;
-    __syncthreads();
-    // ---- phi.0 + ReLU summed over the lane's cars: h1s[lane][k] = sum_n relu(W0[k] . x_n + b0[k])
-    for (int idx = tid; idx < 32 * 16; idx += 256) {
-      const int rr = idx >> 4, k = idx & 15;
-      const int b = row0 + rr;
-      float s = 0.f;
-      if (b < g.B) {
-        const float wa = g.w[PHI0][2 * k], wb = g.w[PHI0][2 * k + 1], bb = g.b[PHI0][k];
-        const float* x = g.data + (long)b * g.N * 2;
-        for (int n = 0; n < g.N; ++n) s += fmaxf(wa * x[2 * n] + wb * x[2 * n + 1] + bb, 0.f);
-      }
-      Ih1[rr * 17 + k] = s;
-    }
-    // ---- phi.2 on the pooled hidden: pooled = W2 * h1s + N*b2   (1 column tile, K=16)
-    load_weight(WS, 17, g.w[PHI2], 32, 16, tid, 256);
-    if (tid < 32) BS[tid] = g.b[PHI2][tid];
-    __syncthreads();
-    if (wave == 0) {
-      f32x16 acc[1];
-      acc[0] = splat((float)g.N * BS[r]);
-      wave_mma<1, 16, 17, 1, 1, 17>(acc, Ih1, WS, lane);
-      store_tile<33>(Ipool, 0, acc[0], lane);
-    }
-    __syncthreads();
-    // ---- rho.0 (32 -> 128, ReLU): one column tile per wave
-    load_weight(WS, 33, g.w[RHO0], 128, 32, tid, 256);
-    if (tid < 128) BS[tid] = g.b[RHO0][tid];
-    __syncthreads();
-    {
-      f32x16 acc[1];
-      acc[0] = splat(BS[wave * 32 + r]);
-      wave_mma<1, 32, 33, 1, 1, 33>(acc, Ipool, WS + wave * 32 * 33, lane);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[0][i] = fmaxf(acc[0][i], 0.f);
-      store_tile<129>(Ir1, wave * 32, acc[0], lane);
-    }
-    __syncthreads();
-    // ---- rho.2 (128 -> 64): wave w takes column tile w&1 and half of K; halves are added in LDS
-    load_weight(WS, 129, g.w[RHO2], 64, 128, tid, 256);
-    if (tid < 64) BS[tid] = g.b[RHO2][tid];
-    __syncthreads();
-    {
-      const int jt = wave & 1, kh = wave >> 1;
-      f32x16 acc[1];
-      acc[0] = splat(kh == 0 ? BS[jt * 32 + r] : 0.f);
-      wave_mma<1, 64, 129, 1, 1, 129>(acc, Ir1 + 64 * kh, WS + jt * 32 * 129 + 64 * kh, lane);
-      if (kh == 0) store_tile<65>(Ir2, jt * 32, acc[0], lane);
-      __syncthreads();
-      if (kh == 1) {
-        const int h = lane >> 5;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) Ir2[drow(i, h) * 65 + jt * 32 + r] += acc[0][i];
-      }
-    }
-    __syncthreads();
-    // ---- heads: [to_mean ; to_logvar] as one [2g][64] weight image
-    zero_img(WS, 32 * 65, tid);
-    __syncthreads();
-    load_weight(WS, 65, g.w[MEAN], gd, 64, tid, 256);
-    load_weight(WS + gd * 65, 65, g.w[LOGVAR], gd, 64, tid, 256);
-    if (tid < 32) BS[tid] = tid < gd ? g.b[MEAN][tid] : (tid < 2 * gd ? g.b[LOGVAR][tid - gd] : 0.f);
-    __syncthreads();
-    if (wave == 0) {
-      f32x16 acc[1];
-      acc[0] = splat(BS[r]);
-      wave_mma<1, 64, 65, 1, 1, 65>(acc, Ir2, WS, lane);
-      store_tile<33>(Iml, 0, acc[0], lane);
-    }
-    __syncthreads();
-    // ---- reparameterisation z = mean + eps * exp(logvar / 2)   (zero-padded to 16 columns)
-    for (int idx = tid; idx < 32 * 16; idx += 256) {
-      const int rr = idx >> 4, j = idx & 15;
-      float zv = 0.f;
-      if (j < gd && row0 + rr < g.B)
-        zv = Iml[rr * 33 + j] + g.eps[(long)(row0 + rr) * gd + j] * expf(0.5f * Iml[rr * 33 + gd + j]);
-      Iz[rr * 17 + j] = zv;
-    }
-    // ---- decoder.0 (g -> 128, ReLU): K padded to 16 with zero weights
-    zero_img(WS, 128 * 17, tid);
-    __syncthreads();
-    load_weight(WS, 17, g.w[DEC0], 128, gd, tid, 256);
-    if (tid < 128) BS[tid] = g.b[DEC0][tid];
-    __syncthreads();
-    {
-      f32x16 acc[1];
-      acc[0] = splat(BS[wave * 32 + r]);
-      wave_mma<1, 16, 17, 1, 1, 17>(acc, Iz, WS + wave * 32 * 17, lane);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[0][i] = fmaxf(acc[0][i], 0.f);
-      store_tile<129>(Id1, wave * 32, acc[0], lane);
-    }
-    __syncthreads();
-    // ---- decoder.2 (128 -> 32): K split over the four waves, partial sums added in LDS in wave order
-    load_weight(WS, 129, g.w[DEC2], 32, 128, tid, 256);
-    if (tid < 32) BS[tid] = g.b[DEC2][tid];
-    __syncthreads();
-    {
-      f32x16 acc[1];
-      acc[0] = splat(wave == 0 ? BS[r] : 0.f);
-      wave_mma<1, 32, 129, 1, 1, 129>(acc, Id1 + 32 * wave, WS + 32 * wave, lane);
-      const int h = lane >> 5;
-      for (int w = 0; w < 4; ++w) {
-        if (wave == w) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            float* p = Id2 + drow(i, h) * 33 + r;
-            *p = w == 0 ? acc[0][i] : *p + acc[0][i];
-          }
-        }
-        __syncthreads();
-      }
-    }
-    // ---- save what the backward pass and the per-car kernel need
-    store_rows(Ih1, 17, g.h1s, 16, row0, g.B, tid);
-    store_rows(Ipool, 33, g.pooled, 32, row0, g.B, tid);
-    store_rows(Ir1, 129, g.r1, 128, row0, g.B, tid);
-    store_rows(Ir2, 65, g.r2, 64, row0, g.B, tid);
-    store_rows(Iml, 33, g.ml, 2 * gd, row0, g.B, tid);
-    store_rows(Iz, 17, g.z, gd, row0, g.B, tid);
-    store_rows(Id1, 129, g.d1, 128, row0, g.B, tid);
-    store_rows(Id2, 33, g.d2, 32, row0, g.B, tid);
-  }
-}
-
-// Column sums of a [32][cols] image, one column per thread (cols <= 128).
 __device__ __forceinline__ float colsum32(const float* img, int ld, int col) {
   float s = 0.f;
 #pragma unroll 8
   for (int rr = 0; rr < 32; ++rr) s += img[rr * ld + col];
   return s;
 }
+// Adds a wave's D tile into img (wave 0 stores, waves 1..3 add, in wave order).
+template <int LD>
+__device__ __forceinline__ void ordered_tile_sum(float* img, const f32x16& t, int wave, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float* p = img + drow(i, h) * LD + r;
+        *p = w == 0 ? t[i] : *p + t[i];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ void lane_load_weights(float* lds, const LaneArgs& g, int tid) {
+  const int gd = g.g;
+  for (int i = tid; i < 32 * 65; i += 256) lds[LW_HEAD + i] = 0.f;
+  for (int i = tid; i < 128 * 17; i += 256) lds[LW_DEC0 + i] = 0.f;
+  __syncthreads();
+  load_weight_v4<32, 16>(lds + LW_PHI2, 17, g.w[PHI2], tid);
+  load_weight_v4<128, 32>(lds + LW_RHO0, 33, g.w[RHO0], tid);
+  load_weight_v4<64, 128>(lds + LW_RHO2, 129, g.w[RHO2], tid);
+  load_weight(lds + LW_HEAD, 65, g.w[MEAN], gd, 64, tid, 256);
+  load_weight(lds + LW_HEAD + gd * 65, 65, g.w[LOGVAR], gd, 64, tid, 256);
+  load_weight(lds + LW_DEC0, 17, g.w[DEC0], 128, gd, tid, 256);
+  load_weight_v4<32, 128>(lds + LW_DEC2, 129, g.w[DEC2], tid);
+  float* bs = lds + LW_BIAS;
+  if (tid < 32) {
+    bs[LB_PHI2 + tid] = g.b[PHI2][tid];
+    bs[LB_DEC2 + tid] = g.b[DEC2][tid];
+    bs[LB_HEAD + tid] = tid < gd ? g.b[MEAN][tid] : (tid < 2 * gd ? g.b[LOGVAR][tid - gd] : 0.f);
+  }
+  if (tid < 128) {
+    bs[LB_RHO0 + tid] = g.b[RHO0][tid];
+    bs[LB_DEC0 + tid] = g.b[DEC0][tid];
+  }
+  if (tid < 64) bs[LB_RHO2 + tid] = g.b[RHO2][tid];
+  __syncthreads();
+}
+
+// Copies the tile's car states (32 lanes x N cars x 2 floats, contiguous in global memory) into LDS.
+__device__ __forceinline__ void stage_cars(float* stage, const LaneArgs& g, int row0, int tid) {
+  const long base = (long)row0 * g.N * 2;
+  const long lim = (long)g.B * g.N * 2;
+  const int n = 64 * g.N;
+  for (int i = tid; i < n; i += 256) stage[i] = (base + i < lim) ? g.data[base + i] : 0.f;
+}
+
+// The forward chain of one 32-lane tile, entirely in LDS.  Ends with a barrier.
+__device__ __forceinline__ void lane_forward_chain(float* lds, const LaneArgs& g, int row0, int tid) {
+  const int lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int gd = g.g;
+  float* bs = lds + LW_BIAS;
+  float* Ih1 = lds + LI_H1;
+  float* Ipool = lds + LI_POOL;
+  float* Ir1 = lds + LI_R1;
+  float* Ir2 = lds + LI_R2;
+  float* Iml = lds + LI_ML;
+  float* Iz = lds + LI_Z;
+  float* Id1 = lds + LI_D1;
+  float* Id2 = lds + LI_D2;
+  const bool staged = g.N <= STAGE_MAX_CARS;
+  if (staged) stage_cars(Id1, g, row0, tid);
+  __syncthreads();
+  // ---- phi.0 + ReLU summed over each lane's cars
+  for (int idx = tid; idx < 32 * 16; idx += 256) {
+    const int rr = idx >> 4, k = idx & 15;
+    const int b = row0 + rr;
+    float s = 0.f;
+    if (b < g.B) {
+      const float wa = g.w[PHI0][2 * k], wb = g.w[PHI0][2 * k + 1], bb = g.b[PHI0][k];
+      if (staged) {
+        const float* x = Id1 + rr * g.N * 2;
+        for (int n = 0; n < g.N; ++n) s += fmaxf(wa * x[2 * n] + wb * x[2 * n + 1] + bb, 0.f);
+      } else {
+        const float* x = g.data + (long)b * g.N * 2;
+        for (int n = 0; n < g.N; ++n) s += fmaxf(wa * x[2 * n] + wb * x[2 * n + 1] + bb, 0.f);
+      }
+    }
+    Ih1[rr * 33 + k] = s;
+  }
+  __syncthreads();
+  // ---- phi.2 on the summed hidden: pooled = W2 h1s + N b2
+  if (wave == 0) {
+    f32x16 acc[1];
+    acc[0] = splat((float)g.N * bs[LB_PHI2 + r]);
+    wave_mma<1, 16, 33, 1, 1, 17>(acc, Ih1, lds + LW_PHI2, lane);
+    store_tile<33>(Ipool, 0, acc[0], lane);
+  }
+  __syncthreads();
+  // ---- rho.0 (32 -> 128, ReLU): one column tile per wave
+  {
+    f32x16 acc[1];
+    acc[0] = splat(bs[LB_RHO0 + wave * 32 + r]);
+    wave_mma<1, 32, 33, 1, 1, 33>(acc, Ipool, lds + LW_RHO0 + wave * 32 * 33, lane);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[0][i] = fmaxf(acc[0][i], 0.f);
+    store_tile<129>(Ir1, wave * 32, acc[0], lane);
+  }
+  __syncthreads();
+  // ---- rho.2 (128 -> 64): wave w takes column tile w&1 and half of K
+  {
+    const int jt = wave & 1, kh = wave >> 1;
+    f32x16 acc[1];
+    acc[0] = splat(kh == 0 ? bs[LB_RHO2 + jt * 32 + r] : 0.f);
+    wave_mma<1, 64, 129, 1, 1, 129>(acc, Ir1 + 64 * kh, lds + LW_RHO2 + jt * 32 * 129 + 64 * kh, lane);
+    if (kh == 0) store_tile<65>(Ir2, jt * 32, acc[0], lane);
+    __syncthreads();
+    if (kh == 1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Ir2[drow(i, h) * 65 + jt * 32 + r] += acc[0][i];
+    }
+  }
+  __syncthreads();
+  // ---- heads (64 -> 2g): K split over the four waves
+  {
+    f32x16 acc[1];
+    acc[0] = splat(wave == 0 ? bs[LB_HEAD + r] : 0.f);
+    wave_mma<1, 16, 65, 1, 1, 65>(acc, Ir2 + 16 * wave, lds + LW_HEAD + 16 * wave, lane);
+    ordered_tile_sum<33>(Iml, acc[0], wave, lane);
+  }
+  // ---- reparameterisation z = mean + eps * exp(logvar / 2), zero-padded to 16 columns
+  for (int idx = tid; idx < 32 * 16; idx += 256) {
+    const int rr = idx >> 4, j = idx & 15;
+    float zv = 0.f;
+    if (j < gd && row0 + rr < g.B)
+      zv = Iml[rr * 33 + j] + g.eps[(long)(row0 + rr) * gd + j] * expf(0.5f * Iml[rr * 33 + gd + j]);
+    Iz[rr * 17 + j] = zv;
+  }
+  __syncthreads();
+  // ---- decoder.0 (g -> 128, ReLU)
+  {
+    f32x16 acc[1];
+    acc[0] = splat(bs[LB_DEC0 + wave * 32 + r]);
+    wave_mma<1, 16, 17, 1, 1, 17>(acc, Iz, lds + LW_DEC0 + wave * 32 * 17, lane);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[0][i] = fmaxf(acc[0][i], 0.f);
+    store_tile<129>(Id1, wave * 32, acc[0], lane);
+  }
+  __syncthreads();
+  // ---- decoder.2 (128 -> 32): K split over the four waves
+  {
+    f32x16 acc[1];
+    acc[0] = splat(wave == 0 ? bs[LB_DEC2 + r] : 0.f);
+    wave_mma<1, 32, 129, 1, 1, 129>(acc, Id1 + 32 * wave, lds + LW_DEC2 + 32 * wave, lane);
+    ordered_tile_sum<33>(Id2, acc[0], wave, lane);
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void vae_lane_forward_kernel(LaneArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  lane_load_weights(lds, g, tid);
+  for (int tile = blockIdx.x; tile < g.tiles; tile += gridDim.x) {
+    const int row0 = tile * 32;
+    lane_forward_chain(lds, g, row0, tid);
+    store_rows32(lds + LI_D2, g.d2, row0, g.B, tid);
+    __syncthreads();
+  }
+}
 
 __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  float* WS = lds + LN_WS;
-  float* IA = lds + LN_A;      // [32][129]: d1, later r1
-  float* IB = lds + LN_B;      // [32][129]: dd1, later dr1
-  float* IC = lds + LN_C;      // [32][65]: r2
-  float* ID = lds + LN_D;      // [32][65]: dr2
-  float* IE = lds + LN_E;      // [32][33]: dd2, later pooled
-  float* IF = lds + LN_F;      // [32][33]: ml, later dpooled
-  float* IG = lds + LN_G;      // [32][33]: dml
-  float* IH = lds + LN_H;      // [32][33]: z / dz (17-wide), later h1s and t = dpooled*Wphi2
   const int gd = g.g;
+  float* Ih1 = lds + LI_H1;
+  float* Ipool = lds + LI_POOL;
+  float* Ir1 = lds + LI_R1;     // r1, then dr1
+  float* Ir2 = lds + LI_R2;     // r2, then dr2, then scratch of the phi.0 backward
+  float* Iml = lds + LI_ML;     // mean|logvar, then dpooled
+  float* Iz = lds + LI_Z;
+  float* Id1 = lds + LI_D1;     // d1, then dd1, then staged car states
+  float* Id2 = lds + LI_D2;     // dd2
+  float* Idml = lds + LI_DML;
+  float* Itmp = lds + LI_TMP;   // dz, then t = dpooled * W_phi2
+  lane_load_weights(lds, g, tid);
 
   // weight-gradient tiles owned by this wave, kept across tiles
   f32x16 aDec2 = splat(0.f), aDec0 = splat(0.f), aHead = splat(0.f), aRho2a = splat(0.f), aRho2b = splat(0.f);
   f32x16 aRho0 = splat(0.f), aPhi2 = splat(0.f);
   // bias gradients: thread tid owns column tid of each layer
   float bDec2 = 0.f, bDec0 = 0.f, bHead = 0.f, bRho2 = 0.f, bRho0 = 0.f, bPhi2 = 0.f;
-  float gPhi0a = 0.f, gPhi0b = 0.f, gPhi0c = 0.f;     // threads 0..15: dW_phi0[k][0], [k][1], db_phi0[k]
+  float gPhi0a = 0.f, gPhi0b = 0.f, gPhi0c = 0.f;     // threads 0..47: dW_phi0[k][0], dW_phi0[k][1], db_phi0[k]
   float klacc = 0.f;
 
   for (int tile = blockIdx.x; tile < g.tiles; tile += gridDim.x) {
     const int row0 = tile * 32;
+    lane_forward_chain(lds, g, row0, tid);
+    load_rows32(Id2, g.d_d2, row0, g.B, tid);
     __syncthreads();
-    load_rows(IE, 33, g.d_d2, 32, row0, g.B, tid);
-    load_rows(IA, 129, g.d1, 128, row0, g.B, tid);
-    load_weight(WS, 129, g.w[DEC2], 32, 128, tid, 256);
-    __syncthreads();
-    // ---- decoder.2 backward: dW[32][128] += dd2^T d1 (tile `wave`), db, dd1 = (dd2 W) o relu'(d1)
+    // ---- decoder.2 backward: dW[32][128] += dd2^T d1, db, dd1 = (dd2 W) o relu'(d1) in place (column block `wave`)
     {
       f32x16 acc[1] = {aDec2};
-      wave_mma<1, 32, 1, 33, 129, 1>(acc, IE, IA + 32 * wave, lane);
+      wave_mma<1, 32, 1, 33, 129, 1>(acc, Id2, Id1 + 32 * wave, lane);
       aDec2 = acc[0];
-      if (tid < 32) bDec2 += colsum32(IE, 33, tid);
+      if (tid < 32) bDec2 += colsum32(Id2, 33, tid);
       f32x16 d[1];
       d[0] = splat(0.f);
-      wave_mma<1, 32, 33, 1, 129, 1>(d, IE, WS + 32 * wave, lane);
+      wave_mma<1, 32, 33, 1, 129, 1>(d, Id2, lds + LW_DEC2 + 32 * wave, lane);
+      wave_sync();
 #pragma unroll
-      for (int i = 0; i < 16; ++i)
-        IB[drow(i, h) * 129 + 32 * wave + r] = IA[drow(i, h) * 129 + 32 * wave + r] > 0.f ? d[0][i] : 0.f;
+      for (int i = 0; i < 16; ++i) {
+        float* p = Id1 + drow(i, h) * 129 + 32 * wave + r;
+        *p = *p > 0.f ? d[0][i] : 0.f;
+      }
     }
     __syncthreads();
-    // ---- decoder.0 backward: dW[128][g] += dd1^T z (row tile `wave`), db, dz = dd1 W
-    zero_img(IH, 32 * 33, tid);
-    zero_img(WS, 128 * 17, tid);
-    __syncthreads();
-    load_rows(IH, 17, g.z, gd, row0, g.B, tid);
-    load_weight(WS, 17, g.w[DEC0], 128, gd, tid, 256);
-    load_rows(IF, 33, g.ml, 2 * gd, row0, g.B, tid);
-    __syncthreads();
+    // ---- decoder.0 backward: dW[128][g] += dd1^T z (row tile `wave`), db, dz = dd1 W (K split over waves)
     {
       f32x16 acc[1] = {aDec0};
-      wave_mma<1, 32, 1, 129, 17, 1>(acc, IB + 32 * wave, IH, lane);
+      wave_mma<1, 32, 1, 129, 17, 1>(acc, Id1 + 32 * wave, Iz, lane);
       aDec0 = acc[0];
-      if (tid < 128) bDec0 += colsum32(IB, 129, tid);
-    }
-    __syncthreads();      // z image is consumed; dz overwrites it below
-    if (wave == 0) {
-      // dz[32][g] = dd1[32][128] * W_dec0[128][g]   (columns >= g read zero weights)
+      if (tid < 128) bDec0 += colsum32(Id1, 129, tid);
       f32x16 d[1];
       d[0] = splat(0.f);
-      wave_mma<1, 128, 129, 1, 17, 1>(d, IB, WS, lane);
-      store_tile<33>(IG, 0, d[0], lane);       // dz parked in IG columns 0..g-1
+      wave_mma<1, 32, 129, 1, 17, 1>(d, Id1 + 32 * wave, lds + LW_DEC0 + 32 * wave * 17, lane);
+      ordered_tile_sum<33>(Itmp, d[0], wave, lane);     // columns >= 17 are junk and never read
     }
-    __syncthreads();
     // ---- latent gradient (KL + reparameterisation): dml = [dz + mean | dz*eps*0.5*std + 0.5*(exp(lv)-1) | 0...]
     for (int idx = tid; idx < 32 * 32; idx += 256) {
       const int rr = idx >> 5, c = idx & 31;
       float outv = 0.f;
       if (c < 2 * gd && row0 + rr < g.B) {
         const int j = c < gd ? c : c - gd;
-        const float mean = IF[rr * 33 + j], lv = IF[rr * 33 + gd + j];
-        const float dz = IG[rr * 33 + j];
+        const float mean = Iml[rr * 33 + j], lv = Iml[rr * 33 + gd + j];
+        const float dz = Itmp[rr * 33 + j];
         if (c < gd) {
           outv = dz + mean;
           klacc += -0.5f * (1.f + lv - mean * mean - expf(lv));
@@ -663,111 +714,90 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
           outv = dz * g.eps[(long)(row0 + rr) * gd + j] * 0.5f * expf(0.5f * lv) + 0.5f * (expf(lv) - 1.f);
         }
       }
-      IH[rr * 33 + c] = outv;
+      Idml[rr * 33 + c] = outv;
     }
     __syncthreads();
-    // dml now lives in IH columns 0..2g-1, zeros beyond
-    // ---- heads backward: dW[2g][64] += dml^T r2 (column tile wave&1, waves 0,1), db, dr2 = dml W (waves 2,3)
-    load_rows(IC, 65, g.r2, 64, row0, g.B, tid);
-    zero_img(WS, 32 * 65, tid);
-    __syncthreads();
-    load_weight(WS, 65, g.w[MEAN], gd, 64, tid, 256);
-    load_weight(WS + gd * 65, 65, g.w[LOGVAR], gd, 64, tid, 256);
-    __syncthreads();
-    if (wave < 2) {
-      f32x16 acc[1] = {aHead};
-      wave_mma<1, 32, 1, 33, 65, 1>(acc, IH, IC + 32 * wave, lane);
-      aHead = acc[0];
-    } else {
+    // ---- heads backward: dW[2g][64] += dml^T r2 (waves 0,1), dr2 = dml W (waves 2,3; replaces r2 afterwards)
+    {
       f32x16 d[1];
       d[0] = splat(0.f);
-      wave_mma<1, 32, 33, 1, 65, 1>(d, IH, WS + 32 * (wave - 2), lane);
-      store_tile<65>(ID, 32 * (wave - 2), d[0], lane);
+      if (wave < 2) {
+        f32x16 acc[1] = {aHead};
+        wave_mma<1, 32, 1, 33, 65, 1>(acc, Idml, Ir2 + 32 * wave, lane);
+        aHead = acc[0];
+      } else {
+        wave_mma<1, 32, 33, 1, 65, 1>(d, Idml, lds + LW_HEAD + 32 * (wave - 2), lane);
+      }
+      if (tid < 32) bHead += colsum32(Idml, 33, tid);
+      __syncthreads();
+      if (wave >= 2) store_tile<65>(Ir2, 32 * (wave - 2), d[0], lane);
     }
-    if (tid < 32) bHead += colsum32(IH, 33, tid);
     __syncthreads();
-    // ---- rho.2 backward: dW[64][128] += dr2^T r1 (8 tiles, two per wave), db, dr1 = (dr2 W) o relu'(r1)
-    load_rows(IA, 129, g.r1, 128, row0, g.B, tid);
-    load_weight(WS, 129, g.w[RHO2], 64, 128, tid, 256);
-    __syncthreads();
+    // ---- rho.2 backward: dW[64][128] += dr2^T r1 (two tiles per wave), db, dr1 = (dr2 W) o relu'(r1) in place
     {
       const int it = wave >> 1, jt0 = (wave & 1) * 2;
       f32x16 acc[2] = {aRho2a, aRho2b};
-      wave_mma<2, 32, 1, 65, 129, 1>(acc, ID + 32 * it, IA + 32 * jt0, lane);
+      wave_mma<2, 32, 1, 65, 129, 1>(acc, Ir2 + 32 * it, Ir1 + 32 * jt0, lane);
       aRho2a = acc[0];
       aRho2b = acc[1];
-      if (tid < 64) bRho2 += colsum32(ID, 65, tid);
+      if (tid < 64) bRho2 += colsum32(Ir2, 65, tid);
       f32x16 d[1];
       d[0] = splat(0.f);
-      wave_mma<1, 64, 65, 1, 129, 1>(d, ID, WS + 32 * wave, lane);
+      wave_mma<1, 64, 65, 1, 129, 1>(d, Ir2, lds + LW_RHO2 + 32 * wave, lane);
+      __syncthreads();                                  // every wave is done reading r1
 #pragma unroll
-      for (int i = 0; i < 16; ++i)
-        IB[drow(i, h) * 129 + 32 * wave + r] = IA[drow(i, h) * 129 + 32 * wave + r] > 0.f ? d[0][i] : 0.f;
+      for (int i = 0; i < 16; ++i) {
+        float* p = Ir1 + drow(i, h) * 129 + 32 * wave + r;
+        *p = *p > 0.f ? d[0][i] : 0.f;
+      }
     }
     __syncthreads();
-    // ---- rho.0 backward: dW[128][32] += dr1^T pooled (row tile `wave`), db, dpooled = dr1 W
-    load_rows(IE, 33, g.pooled, 32, row0, g.B, tid);
-    load_weight(WS, 33, g.w[RHO0], 128, 32, tid, 256);
-    __syncthreads();
+    // ---- rho.0 backward: dW[128][32] += dr1^T pooled (row tile `wave`), db, dpooled = dr1 W (K split) -> ml slot
     {
       f32x16 acc[1] = {aRho0};
-      wave_mma<1, 32, 1, 129, 33, 1>(acc, IB + 32 * wave, IE, lane);
+      wave_mma<1, 32, 1, 129, 33, 1>(acc, Ir1 + 32 * wave, Ipool, lane);
       aRho0 = acc[0];
-      if (tid < 128) bRho0 += colsum32(IB, 129, tid);
-      // dpooled: K = 128 split over the waves, partial sums added in LDS in wave order
+      if (tid < 128) bRho0 += colsum32(Ir1, 129, tid);
       f32x16 d[1];
       d[0] = splat(0.f);
-      wave_mma<1, 32, 129, 1, 33, 1>(d, IB + 32 * wave, WS + 32 * wave * 33, lane);
-      for (int w = 0; w < 4; ++w) {
-        if (wave == w) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            float* p = IF + drow(i, h) * 33 + r;
-            *p = w == 0 ? d[0][i] : *p + d[0][i];
-          }
-        }
-        __syncthreads();
-      }
+      wave_mma<1, 32, 129, 1, 33, 1>(d, Ir1 + 32 * wave, lds + LW_RHO0 + 32 * wave * 33, lane);
+      ordered_tile_sum<33>(Iml, d[0], wave, lane);
     }
-    // ---- phi.2 backward on the pooled hidden: dW[32][16] += dpooled^T h1s, db = N * colsum(dpooled),
-    //      t = dpooled W_phi2 (gradient at every car's hidden layer of that lane, before its ReLU mask)
-    zero_img(IH, 32 * 33, tid);
-    __syncthreads();
-    load_rows(IH, 33, g.h1s, 16, row0, g.B, tid);
-    load_weight(WS, 17, g.w[PHI2], 32, 16, tid, 256);
-    __syncthreads();
+    // ---- phi.2 backward on the summed hidden: dW[32][16] += dpooled^T h1s, db = N colsum(dpooled),
+    //      t = dpooled W_phi2 (gradient at the hidden layer of every car of the lane, before its ReLU mask)
     if (wave == 0) {
       f32x16 acc[1] = {aPhi2};
-      wave_mma<1, 32, 1, 33, 33, 1>(acc, IF, IH, lane);
+      wave_mma<1, 32, 1, 33, 33, 1>(acc, Iml, Ih1, lane);       // columns >= 16 are junk, dropped at the end
       aPhi2 = acc[0];
-    }
-    if (tid < 32) bPhi2 += (float)g.N * colsum32(IF, 33, tid);
-    if (wave == 1) {
+    } else if (wave == 1) {
       f32x16 d[1];
       d[0] = splat(0.f);
-      wave_mma<1, 32, 33, 1, 17, 1>(d, IF, WS, lane);    // columns >= 16 read past the [32][17] image: discarded below
+      wave_mma<1, 32, 33, 1, 17, 1>(d, Iml, lds + LW_PHI2, lane);
       if (r < 16) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) IG[drow(i, h) * 33 + r] = d[0][i];
+        for (int i = 0; i < 16; ++i) Itmp[drow(i, h) * 33 + r] = d[0][i];
       }
     }
+    if (tid < 32) bPhi2 += (float)g.N * colsum32(Iml, 33, tid);
+    const bool staged = g.N <= STAGE_MAX_CARS;
+    if (staged) stage_cars(Id1, g, row0, tid);            // dd1 is dead: reuse its slot
     __syncthreads();
-    // ---- phi.0 backward: per (lane, hidden unit) walk the cars again, apply the ReLU mask
+    // ---- phi.0 backward: per (lane, hidden unit) walk the cars again and apply the ReLU mask
     {
-      float* red = IC;       // [32][3*16] partials, r2 image is free now
+      float* red = Ir2;       // [32][49] partial sums
       for (int idx = tid; idx < 32 * 16; idx += 256) {
         const int rr = idx >> 4, k = idx & 15;
         const int b = row0 + rr;
         float a0 = 0.f, a1 = 0.f, c = 0.f;
         if (b < g.B) {
           const float wa = g.w[PHI0][2 * k], wb = g.w[PHI0][2 * k + 1], bb = g.b[PHI0][k];
-          const float* x = g.data + (long)b * g.N * 2;
+          const float* x = staged ? Id1 + rr * g.N * 2 : g.data + (long)b * g.N * 2;
           for (int n = 0; n < g.N; ++n) {
             const float x0 = x[2 * n], x1 = x[2 * n + 1];
             if (wa * x0 + wb * x1 + bb > 0.f) { a0 += x0; a1 += x1; c += 1.f; }
           }
         }
-        const float t = IG[rr * 33 + k];
+        const float t = Itmp[rr * 33 + k];
         red[rr * 49 + k] = t * a0;
         red[rr * 49 + 16 + k] = t * a1;
         red[rr * 49 + 32 + k] = t * c;
@@ -779,6 +809,7 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
         if (tid < 16) gPhi0a += s; else if (tid < 32) gPhi0b += s; else gPhi0c += s;
       }
     }
+    __syncthreads();
   }
 
   // ---- write this workgroup's slab
@@ -794,7 +825,6 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
   put_tile(g.off.w[DEC2], 128, 32, 32 * wave, 128, aDec2);
   put_tile(g.off.w[DEC0] + (long)32 * wave * gd, gd, 32, 0, gd, aDec0);
   if (wave < 2) {
-    // rows 0..g-1 -> to_mean, rows g..2g-1 -> to_logvar; columns 32*wave..
     const int col = 32 * wave + r;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -875,7 +905,7 @@ __global__ __launch_bounds__(256) void vae_reduce_grads_kernel(const float* __re
 }
 
 struct Ws {
-  float *h1s, *pooled, *r1, *r2, *ml, *z, *d1, *d2, *d_d2, *loss_part, *kl_part, *slab;
+  float *d2, *d_d2, *loss_part, *kl_part, *slab;
   long total;
 };
 
@@ -897,13 +927,6 @@ static Ws carve(float* ws, int B, int N, int g, long n_flat) {
   Ws w;
   long off = 0;
   auto take = [&](long n) { float* p = ws ? ws + off : nullptr; off += a64(n); return p; };
-  w.h1s = take((long)B * 16);
-  w.pooled = take((long)B * 32);
-  w.r1 = take((long)B * 128);
-  w.r2 = take((long)B * 64);
-  w.ml = take((long)B * 2 * g);
-  w.z = take((long)B * g);
-  w.d1 = take((long)B * 128);
   w.d2 = take((long)B * 32);
   w.d_d2 = take((long)B * 32);
   w.loss_part = take(256);
@@ -975,7 +998,7 @@ int hhrl_vae_train_step(const float* params, float* grads, const long* offsets, 
     la.w[l] = params + off.w[l];
     la.b[l] = params + off.b[l];
   }
-  la.h1s = w.h1s; la.pooled = w.pooled; la.r1 = w.r1; la.r2 = w.r2; la.ml = w.ml; la.z = w.z; la.d1 = w.d1; la.d2 = w.d2;
+  la.d2 = w.d2;
   la.d_d2 = w.d_d2;
   la.slab = w.slab;
   la.kl_part = w.kl_part;
@@ -984,7 +1007,7 @@ int hhrl_vae_train_step(const float* params, float* grads, const long* offsets, 
 
   const double lane_macs = 16.0 * 2 * N + 512 + 4096 + 8192 + 128.0 * g + 128.0 * g + 4096;
   {
-    ProfScope ps("vae_lane_forward_kernel", st, 2.0 * lane_macs * B, 4.0 * B * (2.0 * N + g + 16 + 32 + 128 + 64 + 3 * g + 128 + 32));
+    ProfScope ps("vae_lane_forward_kernel", st, 2.0 * lane_macs * B, 4.0 * B * (2.0 * N + g + 32));
     hipLaunchKernelGGL(vae_lane_forward_kernel, dim3(nlane), dim3(256), LN_LDS_FLOATS * 4, st, la);
     HHRL_TRY(launch_status("vae_lane_forward_kernel"));
   }
@@ -1013,7 +1036,7 @@ int hhrl_vae_train_step(const float* params, float* grads, const long* offsets, 
     HHRL_TRY(launch_status("vae_car_fwd_bwd_kernel"));
   }
   {
-    ProfScope ps("vae_lane_backward_kernel", st, 4.0 * lane_macs * B, 4.0 * B * (2.0 * N + g + 32 + 16 + 32 + 128 + 64 + 3 * g + 128));
+    ProfScope ps("vae_lane_backward_kernel", st, 4.0 * lane_macs * B, 4.0 * B * (2.0 * N + g + 32));
     hipLaunchKernelGGL(vae_lane_backward_kernel, dim3(nlane), dim3(256), LN_LDS_FLOATS * 4, st, la);
     HHRL_TRY(launch_status("vae_lane_backward_kernel"));
   }
