@@ -133,6 +133,26 @@ __global__ __launch_bounds__(256) void adam_scalar_kernel(float* p, const float*
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) adam_one(p[i], g[i], m[i], v[i], k);
 }
 
+// Same update with the scalars read from device memory, so that a captured HIP graph can be
+// replayed with a new step count / learning rate (the host refreshes the 8 floats per step).
+// Writes the scalars of one Adam step into device memory (they travel as kernel arguments, so
+// the host may stage the next step at once).
+__global__ void adam_stage_kernel(float* hyper, AdamK k) {
+  if (threadIdx.x == 0) {
+    hyper[0] = k.step_size; hyper[1] = k.beta1; hyper[2] = k.beta2; hyper[3] = k.one_minus_b1;
+    hyper[4] = k.one_minus_b2; hyper[5] = k.bc2_sqrt; hyper[6] = k.eps; hyper[7] = k.gscale;
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* p, const float* __restrict__ g, float* m, float* v, long n,
+                                                       const float* __restrict__ hyper) {
+  AdamK k;
+  k.step_size = hyper[0]; k.beta1 = hyper[1]; k.beta2 = hyper[2]; k.one_minus_b1 = hyper[3];
+  k.one_minus_b2 = hyper[4]; k.bc2_sqrt = hyper[5]; k.eps = hyper[6]; k.gscale = hyper[7];
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) adam_one(p[i], g[i], m[i], v[i], k);
+}
+
 __global__ __launch_bounds__(256) void polyak_kernel(float* t, const float* __restrict__ p, long n, float tau, float om, int vec) {
   const long stride = (long)gridDim.x * blockDim.x;
   if (vec) {
@@ -246,6 +266,33 @@ int hhrl_adam_step(float* p, const float* g, float* m, float* v, long n, double 
     hipLaunchKernelGGL(adam_scalar_kernel, dim3(stream_grid(n)), dim3(256), 0, st, p, g, m, v, n, k);
   }
   return launch_status("adam_kernel");
+}
+
+int hhrl_adam_stage(float* hyper_dev, double lr, double beta1, double beta2, double eps, int step, double grad_scale,
+                    void* stream) {
+  HHRL_REQUIRE(hyper_dev && step >= 1, "adam_stage: null pointer or step < 1");
+  const double bc1 = 1.0 - std::pow(beta1, step);
+  const double bc2 = 1.0 - std::pow(beta2, step);
+  AdamK k;
+  k.step_size = (float)(lr / bc1);
+  k.beta1 = (float)beta1;
+  k.beta2 = (float)beta2;
+  k.one_minus_b1 = (float)(1.0 - beta1);
+  k.one_minus_b2 = (float)(1.0 - beta2);
+  k.bc2_sqrt = (float)std::sqrt(bc2);
+  k.eps = (float)eps;
+  k.gscale = (float)grad_scale;
+  hipLaunchKernelGGL(adam_stage_kernel, dim3(1), dim3(64), 0, as_stream(stream), hyper_dev, k);
+  return launch_status("adam_stage_kernel");
+}
+
+int hhrl_adam_step_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper_dev, void* stream) {
+  HHRL_REQUIRE(p && g && m && v && hyper_dev, "adam_step_dev: null pointer");
+  HHRL_REQUIRE(n > 0, "adam_step_dev: n=%ld", n);
+  hipStream_t st = as_stream(stream);
+  ProfScope ps("adam_dev_kernel", st, 0.0, 28.0 * n);
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(stream_grid(n)), dim3(256), 0, st, p, g, m, v, n, hyper_dev);
+  return launch_status("adam_dev_kernel");
 }
 
 int hhrl_polyak_update(float* target, const float* p, long n, double tau, void* stream) {

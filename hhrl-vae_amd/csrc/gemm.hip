@@ -119,9 +119,122 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
   }
 }
 
+// Latency-oriented variant for small outputs (batch-64 agent updates, LSTM steps).
+// One workgroup = one 32x32 output tile; its four waves each take a quarter of
+// the reduction range, staging their operand chunks in wave-private LDS (no
+// workgroup barrier in the loop), and the four partial tiles are summed in LDS
+// in wave order.  Many small workgroups instead of a few long-running ones.
+constexpr int SKC = 64;   // reduction elements staged per wave per chunk
+
+__global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
+  __shared__ float stage[4][2][SKC][33];
+  __shared__ float part[4][32][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  const int zbeg = blockIdx.z * g.k_chunk;
+  const int zend = min(g.K, zbeg + g.k_chunk);
+  // this wave's share of [zbeg, zend), a multiple of 2 except at the end
+  const int span = (((zend - zbeg + 3) / 4) + 1) & ~1;
+  const int kbeg = min(zend, zbeg + wave * span), kend = min(zend, kbeg + span);
+  float (*As)[33] = stage[wave][0];
+  float (*Bs)[33] = stage[wave][1];
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+  for (int k0 = kbeg; k0 < kend; k0 += SKC) {
+    const int kc = min(SKC, kend - k0);
+    const int kc2 = (kc + 1) & ~1;
+    // Stage both operand chunks: every lane first issues all 64 of its loads (one exposed
+    // memory latency per chunk), then writes them to LDS.  As[k][i] = A(i0+i, k0+k), Bs[k][j] = B(k0+k, j0+j).
+    float av[32], bv[32];
+    if (g.a_kcontig) {
+      const long base = (long)i0 * g.a_si + (long)(k0 + lane) * g.a_sk;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) av[i] = (lane < kc && i0 + i < g.M) ? g.A[base + (long)i * g.a_si] : 0.f;
+    } else {
+      const long base = (long)(i0 + r) * g.a_si + (long)(k0 + h) * g.a_sk;
+#pragma unroll
+      for (int t = 0; t < 32; ++t) av[t] = (2 * t + h < kc && i0 + r < g.M) ? g.A[base + (long)(2 * t) * g.a_sk] : 0.f;
+    }
+    if (g.b_kcontig) {
+      const long base = (long)(k0 + lane) * g.b_sk + (long)j0 * g.b_sj;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) bv[j] = (lane < kc && j0 + j < g.N) ? g.B[base + (long)j * g.b_sj] : 0.f;
+    } else {
+      const long base = (long)(k0 + h) * g.b_sk + (long)(j0 + r) * g.b_sj;
+#pragma unroll
+      for (int t = 0; t < 32; ++t) bv[t] = (2 * t + h < kc && j0 + r < g.N) ? g.B[base + (long)(2 * t) * g.b_sk] : 0.f;
+    }
+    if (g.a_kcontig) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) As[lane][i] = av[i];
+    } else {
+#pragma unroll
+      for (int t = 0; t < 32; ++t) As[2 * t + h][r] = av[t];
+    }
+    if (g.b_kcontig) {
+#pragma unroll
+      for (int j = 0; j < 32; ++j) Bs[lane][j] = bv[j];
+    } else {
+#pragma unroll
+      for (int t = 0; t < 32; ++t) Bs[2 * t + h][r] = bv[t];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int k = 0; k < kc2; k += 2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k + h][r], Bs[k + h][r], acc, 0, 0, 0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  // when k-contiguous staging left rows of the chunk beyond kc untouched they were zero-filled above
+#pragma unroll
+  for (int i = 0; i < 16; ++i) part[wave][(i & 3) + 8 * (i >> 2) + 4 * h][r] = acc[i];
+  __syncthreads();
+  // fixed-order sum of the four partial tiles, epilogue, store: thread -> (row = tid/8 + 32*u..., col)
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int idx = u * 256 + tid;
+    const int row = idx >> 5, col = idx & 31;
+    const int gi = i0 + row, gj = j0 + col;
+    if (gi >= g.M || gj >= g.N) continue;
+    float v = (part[0][row][col] + part[1][row][col]) + (part[2][row][col] + part[3][row][col]);
+    float* c = g.C + (long)gi * g.ldc + gj;
+    if (g.mode == 2) {
+      unsafeAtomicAdd(c, v);
+    } else {
+      if (g.bias) v += g.bias[gj];
+      if (g.mode == 1) v += *c;
+      *c = act_apply(v, g.act);
+    }
+  }
+}
+
 int gemm(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj, float* C, long ldc,
          int M, int N, int K, const float* bias, int act, int mode, hipStream_t st) {
   GemmArgs g{A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, M, N, K, K, act, mode, a_sk == 1, b_sk == 1};
+  const long tiles32 = (long)ceil_div(M, 32) * ceil_div(N, 32);
+  if (tiles32 <= 512) {
+    int gz = 1;
+    if (mode == 2 && K > 1024) {
+      // weight gradients over many rows: spread the reduction over workgroups too (atomics combine)
+      long want = 1024 / tiles32;
+      if (want < 1) want = 1;
+      gz = (int)(ceil_div(K, 512) < want ? ceil_div(K, 512) : want);
+      int chunk = ceil_div(K, gz);
+      chunk = (chunk + 7) & ~7;
+      g.k_chunk = chunk;
+      gz = ceil_div(K, chunk);
+    }
+    dim3 grid(ceil_div(N, 32), ceil_div(M, 32), gz);
+    ProfScope ps("gemm_small_kernel", st, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + (double)M * N));
+    hipLaunchKernelGGL(gemm_small_kernel, grid, dim3(256), 0, st, g);
+    return launch_status("gemm_small_kernel");
+  }
   const int TM = M > 1024 ? 2 : 1;
   const int TN = N > 64 ? 2 : 1;
   const int gx = ceil_div(N, 64 * TN), gy = ceil_div(M, 64 * TM);

@@ -27,6 +27,26 @@ class FlatAdam:
         self.base_lr = float(lr)
         self.step_count = 0
         self._lib = _lib.load()
+        self._hyper_dev = None
+
+    # -- graph-replayable form: scalars in device memory -------------------
+    def stage_next_step(self, grad_scale: float = 1.0) -> None:
+        """Enqueues the kernel scalars of the NEXT step (count + 1, current lr)
+        into device memory on the current stream; `step_dev` launches can then
+        be replayed from a captured graph.  Call `commit_step` once the step
+        has been enqueued."""
+        if self._hyper_dev is None:
+            self._hyper_dev = torch.zeros(8, dtype=torch.float32, device=self.p.data.device)
+        _lib.check(self._lib.hhrl_adam_stage(self._hyper_dev.data_ptr(), self.lr, self.beta1, self.beta2, self.eps,
+                                             self.step_count + 1, float(grad_scale), _lib.stream_ptr()))
+
+    def step_dev(self) -> None:
+        _lib.check(self._lib.hhrl_adam_step_dev(
+            self.p.base_ptr, self.g.base_ptr, self.m.base_ptr, self.v.base_ptr, self.p.layout.size,
+            self._hyper_dev.data_ptr(), _lib.stream_ptr()))
+
+    def commit_step(self) -> None:
+        self.step_count += 1
 
     def zero_grad(self) -> None:
         self.g.data.zero_()

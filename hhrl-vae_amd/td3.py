@@ -157,16 +157,25 @@ class CriticNet:
             w = self._work[B] = _CriticWork(self, B, self.dev)
         return w
 
-    def features(self, B: int, obs: Sequence[Tuple[int, int]], goal: Optional[int], ld_goal: int) -> None:
-        """State part of the head input: LSTM features or raw observations, then the goal."""
+    def feature(self, k: int, B: int, o_ptr: int, o_ld: int) -> None:
+        """Stream k's part of the head input: its LSTM feature or its raw observation."""
         w = self.work(B)
-        for s, lstm, col, (o_ptr, o_ld), ws in zip(self.fam.streams, self.lstms, self.feat_cols, obs, w.lstm_ws):
-            if lstm is not None:
-                lstm.fwd(o_ptr, o_ld, P(w.xu, col), self.D, ws, B)
-            else:
-                ops.copy2d(o_ptr, o_ld, P(w.xu, col), self.D, B, s.o)
+        s, lstm, col = self.fam.streams[k], self.lstms[k], self.feat_cols[k]
+        if lstm is not None:
+            lstm.fwd(o_ptr, o_ld, P(w.xu, col), self.D, w.lstm_ws[k], B)
+        else:
+            ops.copy2d(o_ptr, o_ld, P(w.xu, col), self.D, B, s.o)
+
+    def set_goal(self, B: int, goal: Optional[int], ld_goal: int) -> None:
         if self.fam.goal_dim:
+            w = self.work(B)
             ops.copy2d(goal, ld_goal, P(w.xu, self.goal_col), self.D, B, self.fam.goal_dim)
+
+    def features(self, B: int, obs: Sequence[Tuple[int, int]], goal: Optional[int], ld_goal: int) -> None:
+        """State part of the head input: per-stream features, then the goal."""
+        for k, (o_ptr, o_ld) in enumerate(obs):
+            self.feature(k, B, o_ptr, o_ld)
+        self.set_goal(B, goal, ld_goal)
 
     def set_actions(self, B: int, src: int, ld_src: int) -> None:
         """Joint action block copied from `src` (replay rows keep a1|a2|a3 adjacent)."""
@@ -185,9 +194,16 @@ class CriticNet:
         self.l5.fwd(P(w.b1), h0, P(w.b2), h1, B)
         self.l6.fwd(P(w.b2), h1, P(w.q2), 1, B)
 
-    def backward(self, B: int, both_heads: bool, param_grads: bool) -> None:
+    def lstm_backward(self, k: int, B: int) -> None:
+        """BPTT of stream k's LSTM from its columns of w.d_xu (independent of the other streams)."""
+        w = self.work(B)
+        if self.lstms[k] is not None:
+            self.lstms[k].bwd(P(w.d_xu, self.feat_cols[k]), self.D, w.lstm_ws[k], B)
+
+    def backward(self, B: int, both_heads: bool, param_grads: bool, lstms: bool = True) -> None:
         """Back-propagates w.d_q1 (and w.d_q2) to w.d_xu; with param_grads also
-        into the critic's gradient buffer, including its LSTMs."""
+        into the critic's gradient buffer (its LSTMs too unless lstms=False:
+        the caller then runs lstm_backward per stream)."""
         w = self.work(B)
         h0, h1 = self.h
         has_lstm = any(l is not None for l in self.lstms)
@@ -201,10 +217,9 @@ class CriticNet:
             self.l5.bwd(P(w.b1), h0, P(w.b2), h1, P(w.d_a2), h1, P(w.d_a1), h0, B, param_grads=param_grads)
             self.l4.bwd(P(w.xu), self.D, P(w.b1), h0, P(w.d_a1), h0, P(w.d_xu) if need_dxu else None, self.D, B,
                         dx_accumulate=1, param_grads=param_grads)
-        if param_grads:
-            for lstm, col, ws in zip(self.lstms, self.feat_cols, w.lstm_ws):
-                if lstm is not None:
-                    lstm.bwd(P(w.d_xu, col), self.D, ws, B)
+        if param_grads and lstms:
+            for k in range(len(self.lstms)):
+                self.lstm_backward(k, B)
 
 
 # ------------------------------------------------------------------ replay
@@ -247,7 +262,8 @@ class TD3Learner:
     (:1109-1168), HATD3Double.learn (:479-542), HATD3Triple.learn (:768-838).
     """
 
-    def __init__(self, fam: Family, device: Optional[str] = None, seed: Optional[int] = None, group=None):
+    def __init__(self, fam: Family, device: Optional[str] = None, seed: Optional[int] = None, group=None,
+                 use_graph: bool = True):
         if not torch.cuda.is_available():
             raise RuntimeError("hhrl_vae_amd needs an AMD GPU (no CPU fallback)")
         self._lib = _lib.load()
@@ -281,8 +297,12 @@ class TD3Learner:
         self._rng = torch.Generator(device=dev)
         self._rng.manual_seed(3407)
         self._loss = ops.dev_zeros(2, device=dev)
-        self._pi: Dict[int, List[torch.Tensor]] = {}
-        self._y: Dict[int, torch.Tensor] = {}
+        self._statics: Dict[int, "TD3Learner._Static"] = {}
+        self._graphs: Dict[tuple, "torch.cuda.CUDAGraph"] = {}
+        self._seen: Dict[tuple, int] = {}
+        self.use_graph = bool(use_graph)
+        self._capturing = False
+        self._side_streams: List["torch.cuda.Stream"] = []
         # column offsets inside a replay row
         f = fam
         pos = 0
@@ -307,72 +327,158 @@ class TD3Learner:
         raise NotImplementedError
 
     def _upload(self, rows: np.ndarray) -> torch.Tensor:
-        t = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32))
-        return t.to(self.device, non_blocking=False)
+        return torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32))
 
     # ---- the update -------------------------------------------------------
+    class _Static:
+        """Per-batch-size device buffers with fixed addresses (a captured graph replays on them)."""
+
+        def __init__(self, fam: Family, B: int, dev):
+            self.rows = ops.dev_empty(B, fam.row_width, device=dev)
+            self.noise = [ops.dev_empty(B, a, device=dev) for a in fam.a_dims]
+            self.pi = [ops.dev_empty(B, a, device=dev) for a in fam.a_dims]
+            self.y = ops.dev_empty(B, 1, device=dev)
+
     def learn_rows(self, rows: torch.Tensor, noise: Optional[Sequence] = None, order: Optional[Sequence[int]] = None) -> None:
-        """One TD3 update on a [B, row_width] fp32 device block of replay rows."""
-        fam, lib, st = self.fam, self._lib, _lib.stream_ptr()
+        """One TD3 update on a [B, row_width] fp32 block of replay rows (host or device tensor).
+
+        The kernel sequence of an update depends only on (B, policy step?, actor order); after two
+        eager runs of a given combination it is captured into a HIP graph and replayed, with the
+        per-step scalars of Adam staged in device memory beforehand."""
+        fam = self.fam
         B, W = int(rows.shape[0]), fam.row_width
         if rows.dim() != 2 or rows.shape[1] != W or B == 0:
             raise ValueError("rows must be [B, %d], got %s" % (W, tuple(rows.shape)))
-        rows = rows.contiguous()
+        st = self._statics.get(B)
+        if st is None:
+            st = self._statics[B] = TD3Learner._Static(fam, B, self.device)
+        st.rows.copy_(rows)
         n_act = len(self.actors)
         if noise is None:
-            noise = [torch.randn((B, a), generator=self._rng, device=self.device, dtype=torch.float32) for a in fam.a_dims]
+            for e in st.noise:
+                e.normal_(generator=self._rng)
         else:
-            noise = [torch.as_tensor(np.asarray(e) if not isinstance(e, torch.Tensor) else e, dtype=torch.float32)
-                     .to(self.device).contiguous() for e in noise]
-            for e, a in zip(noise, fam.a_dims):
-                if tuple(e.shape) != (B, a):
-                    raise ValueError("noise must be [%d, %d], got %s" % (B, a, tuple(e.shape)))
+            for e, src, a in zip(st.noise, noise, fam.a_dims):
+                src = torch.as_tensor(np.asarray(src) if not isinstance(src, torch.Tensor) else src, dtype=torch.float32)
+                if tuple(src.shape) != (B, a):
+                    raise ValueError("noise must be [%d, %d], got %s" % (B, a, tuple(src.shape)))
+                e.copy_(src)
         self.total_it += 1
+        policy = self.total_it % self.policy_freq == 0
+        if policy:
+            if order is None:
+                order = np.random.permutation(n_act) if n_act > 1 else [0]
+            order = tuple(int(i) for i in order)
+            if sorted(order) != list(range(n_act)):
+                raise ValueError("order must be a permutation of range(%d)" % n_act)
+        else:
+            order = ()
+        # scalars of the Adam steps this update will take
+        self.critic.opt.stage_next_step()
+        if policy:
+            for a in self.actors:
+                a.opt.stage_next_step()
+        key = (B, policy, order)
+        graph = self._graphs.get(key)
+        if graph is not None:
+            graph.replay()
+        elif self.use_graph and self.group is None and self._seen.get(key, 0) >= 2:
+            graph = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            self._capturing = True
+            try:
+                with torch.cuda.graph(graph):
+                    self._update_body(st, B, policy, order)
+            finally:
+                self._capturing = False
+            self._graphs[key] = graph
+            graph.replay()
+        else:
+            self._seen[key] = self._seen.get(key, 0) + 1
+            self._update_body(st, B, policy, order)
+        # host-side bookkeeping of what was just enqueued
+        self.critic.opt.commit_step()
+        self.critic_sched.step()
+        if policy:
+            for a in self.actors:
+                a.opt.commit_step()
+            for s in self.actor_scheds:
+                s.step()
+        self.last_critic_loss = self._loss
+
+    def _parallel(self, fns) -> None:
+        """Runs independent kernel sequences.  While a graph is being captured
+        each sequence goes to a side stream forked from, and joined back into,
+        the capture stream, so the graph holds them as parallel branches (the
+        per-stream LSTMs of a manager are small and leave most CUs idle on
+        their own); otherwise they simply run in turn."""
+        if not self._capturing or len(fns) < 2:
+            for fn in fns:
+                fn()
+            return
+        main = torch.cuda.current_stream()
+        while len(self._side_streams) < len(fns) - 1:
+            self._side_streams.append(torch.cuda.Stream(device=self.device))
+        fns[0]()
+        for sd, fn in zip(self._side_streams, fns[1:]):
+            sd.wait_stream(main)
+        for sd, fn in zip(self._side_streams, fns[1:]):
+            with torch.cuda.stream(sd):
+                fn()
+        for sd, _ in zip(self._side_streams, fns[1:]):
+            main.wait_stream(sd)
+
+    def _update_body(self, st: "TD3Learner._Static", B: int, policy: bool, order: Sequence[int]) -> None:
+        """The kernel sequence of one update (no host-side state changes)."""
+        fam, lib, sp = self.fam, self._lib, _lib.stream_ptr()
+        W = fam.row_width
+        rows, noise, pi, y = st.rows, st.noise, st.pi, st.y
         inv_n = 1.0 / float(B * self.world_size)
         R = lambda col: P(rows, col)
         goal = R(self.col_goal) if fam.goal_dim else None
         next_goal = R(self.col_next_goal) if fam.goal_dim else None
         obs = [(R(c), W) for c in self.col_obs]
         next_obs = [(R(c), W) for c in self.col_next_obs]
-        if B not in self._pi:
-            self._pi[B] = [ops.dev_empty(B, a, device=self.device) for a in fam.a_dims]
-            self._y[B] = ops.dev_empty(B, 1, device=self.device)
-        pi, y = self._pi[B], self._y[B]
 
         # -- target value (no gradient): algorithm.py:1329-1337 / 785-796
         ct, cw_t = self.critic_target, self.critic_target.work(B)
-        for k, (at, eps) in enumerate(zip(self.actor_targets, noise)):
-            at.forward(B, next_obs[k][0], W, next_goal, W, P(pi[k]), fam.a_dims[k])
-            check(lib.hhrl_td3_smooth_action(P(pi[k]), fam.a_dims[k], P(eps), P(cw_t.xu, ct.act_cols[k]), ct.D, B,
-                                             fam.a_dims[k], st))
-        ct.features(B, next_obs, next_goal, W)
+
+        def target_action(k):
+            def run():
+                self.actor_targets[k].forward(B, next_obs[k][0], W, next_goal, W, P(pi[k]), fam.a_dims[k])
+                check(lib.hhrl_td3_smooth_action(P(pi[k]), fam.a_dims[k], P(noise[k]), P(cw_t.xu, ct.act_cols[k]), ct.D, B,
+                                                 fam.a_dims[k], _lib.stream_ptr()))
+            return run
+        n_str = len(fam.streams)
+        self._parallel([target_action(k) for k in range(len(self.actors))] +
+                       [(lambda k=k: ct.feature(k, B, next_obs[k][0], W)) for k in range(n_str)])
+        ct.set_goal(B, next_goal, W)
         ct.heads(B)
-        check(lib.hhrl_td3_target_q(P(cw_t.q1), P(cw_t.q2), R(self.col_reward), W, fam.gamma, P(y), B, st))
+        check(lib.hhrl_td3_target_q(P(cw_t.q1), P(cw_t.q2), R(self.col_reward), W, fam.gamma, P(y), B, sp))
 
         # -- critic step: :1341-1350 / 799-808
         c, cw = self.critic, self.critic.work(B)
         c.opt.zero_grad()
         self._loss.zero_()
-        c.features(B, obs, goal, W)
+        self._parallel([(lambda k=k: c.feature(k, B, obs[k][0], W)) for k in range(n_str)])
+        c.set_goal(B, goal, W)
         c.set_actions(B, R(self.col_act), W)
         c.heads(B)
-        check(lib.hhrl_twin_mse(P(cw.q1), P(cw.q2), P(y), inv_n, P(self._loss), P(cw.d_q1), P(cw.d_q2), B, st))
-        c.backward(B, both_heads=True, param_grads=True)
+        check(lib.hhrl_twin_mse(P(cw.q1), P(cw.q2), P(y), inv_n, P(self._loss), P(cw.d_q1), P(cw.d_q2), B, sp))
+        c.backward(B, both_heads=True, param_grads=True, lstms=False)
+        self._parallel([(lambda k=k: c.lstm_backward(k, B)) for k in range(n_str)])
         self._allreduce(c.opt.g)
-        c.opt.step()
-        self.critic_sched.step()
+        c.opt.step_dev()
 
         # -- delayed policy step: :1353-1366 / 811-838
-        if self.total_it % self.policy_freq == 0:
-            if order is None:
-                order = np.random.permutation(n_act) if n_act > 1 else [0]
-            order = [int(i) for i in order]
-            if sorted(order) != list(range(n_act)):
-                raise ValueError("order must be a permutation of range(%d)" % n_act)
-            if any(l is not None for l in c.lstms):
-                c.features(B, obs, goal, W)           # LSTM features under the updated critic weights
-            for j, a in enumerate(self.actors):       # joint action written straight into the critic input
-                a.forward(B, obs[j][0], W, goal, W, P(cw.xu, c.act_cols[j]), c.D)
+        if policy:
+            branches = []
+            if any(l is not None for l in c.lstms):   # LSTM features under the updated critic weights
+                branches += [(lambda k=k: c.feature(k, B, obs[k][0], W)) for k in range(n_str)]
+            # joint action written straight into the critic input
+            branches += [(lambda j=j, a=a: a.forward(B, obs[j][0], W, goal, W, P(cw.xu, c.act_cols[j]), c.D))
+                         for j, a in enumerate(self.actors)]
+            self._parallel(branches)
             for n, i in enumerate(order):
                 a = self.actors[i]
                 c.heads(B, q1_only=True)
@@ -381,16 +487,12 @@ class TD3Learner:
                 a.opt.zero_grad()
                 a.backward(B, P(cw.xu, c.act_cols[i]), c.D, P(cw.d_xu, c.act_cols[i]), c.D)
                 self._allreduce(a.opt.g)
-                a.opt.step()
+                a.opt.step_dev()
                 if n + 1 < len(order):                # later actors see this actor's new policy
                     a.forward(B, obs[i][0], W, goal, W, P(cw.xu, c.act_cols[i]), c.D)
             ops.polyak(self.critic_target.params, self.critic.params, fam.tau)
             for a, t in zip(self.actors, self.actor_targets):
                 ops.polyak(t.params, a.params, fam.tau)
-            for s in self.actor_scheds:
-                s.step()
-        self._keep = (rows, noise)
-        self.last_critic_loss = self._loss
 
     def _allreduce(self, g: FlatBuffer) -> None:
         if self.group is not None:

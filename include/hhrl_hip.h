@@ -159,6 +159,16 @@ int hhrl_lstm_backward(const float* const* params, const float* d_out, int lddo,
  * host, as torch forms them, and only then rounded to fp32 kernel scalars. */
 int hhrl_adam_step(float* p, const float* g, float* m, float* v, long n, double lr,
                    double beta1, double beta2, double eps, int step, double grad_scale, void* stream);
+/* The same update for use inside a captured HIP graph: the eight kernel scalars
+ * (step size with bias correction, betas, 1-betas, sqrt(bias correction 2), eps,
+ * gradient scale) live in DEVICE memory, 8 floats at hyper_dev.
+ * hhrl_adam_stage() enqueues a one-workgroup kernel that writes them for the
+ * given step (outside the graph, before each replay); hhrl_adam_step_dev() is
+ * the capturable launch that reads them. */
+int hhrl_adam_stage(float* hyper_dev, double lr, double beta1, double beta2, double eps, int step,
+                    double grad_scale, void* stream);
+int hhrl_adam_step_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper_dev,
+                       void* stream);
 /* target = tau*p + (1-tau)*target          (algorithm.py:323-326, 534-539, 827-834, 1163-1166, 1361-1364) */
 int hhrl_polyak_update(float* target, const float* p, long n, double tau, void* stream);
 

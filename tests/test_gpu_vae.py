@@ -168,7 +168,7 @@ def test_vae_fused_matches_layerwise(B, N, g):
     x = torch.from_numpy(gen.gen_lanes(B, N, 9)).cuda()
     eps = torch.randn(B, g, generator=torch.Generator().manual_seed(B * N)).cuda()
     lf, ll = float(ef.loss_and_grads(x, eps)), float(el.loss_and_grads(x, eps))
-    assert_close("loss", lf, ll, rtol=1e-5, atol=0)
+    assert_close("loss", lf, ll, rtol=1e-4, atol=0)
     # two fp32 evaluations in different summation orders: elements above 2e-4 of their tensor's largest
     # entry (1e-5 for small batches) must agree to rtol 1e-4; accuracy itself is judged against the
     # oracle and its fp64 yardstick in test_vae_full_size_vs_oracle
