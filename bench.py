@@ -84,11 +84,13 @@ def agent_update_rates(device, steps: int) -> dict:
     from hhrl_vae_amd.algorithm import HATD3Triple, WorkerTD3
     out = {}
     for name, net, n_rows in (("worker_td3_b64", WorkerTD3(gen.cav_cfg(cap=4096), device=str(device)), 4096),
-                              ("hatd3_triple_b64", HATD3Triple(gen.light_cfg(cap=2048), device=str(device)), 2048)):
+                              ("worker_td3_b4096", WorkerTD3(gen.cav_cfg(cap=8192, batch=4096), device=str(device)), 8192),
+                              ("hatd3_triple_b64", HATD3Triple(gen.light_cfg(cap=2048), device=str(device)), 2048),
+                              ("hatd3_triple_b1024", HATD3Triple(gen.light_cfg(cap=2048, batch=1024), device=str(device)), 2048)):
         rows = np.random.RandomState(3407).uniform(0, 1, size=(n_rows, net.fam.row_width))
         net.memory[:n_rows] = rows
         net.pointer = n_rows
-        for _ in range(4):
+        for _ in range(30):                    # eager runs, then every (policy step, actor order) graph gets captured
             net.learn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -96,8 +98,27 @@ def agent_update_rates(device, steps: int) -> dict:
             net.learn()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        out[name] = {"minibatches_per_s": steps / dt, "ms_per_update": 1e3 * dt / steps}
+        out[name] = {"minibatches_per_s": steps / dt, "ms_per_update": 1e3 * dt / steps,
+                     "rows_per_s": steps * net.batch_size / dt}
     return out
+
+
+def pmc_traffic(workload: str, kernel: str):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary
+    of this workload (rocprofv3 FETCH_SIZE / WRITE_SIZE passes, read bytes
+    doubled as gfx950 requires); None when no summary covers the workload."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        k = d.get("kernels", {}).get(kernel)
+        if d.get("workload") == workload and k is not None:
+            best = {"bytes": k["hbm_bytes_per_launch"], "source": os.path.relpath(path, ROOT)}
+    return best
 
 
 def main() -> None:
@@ -156,6 +177,19 @@ def main() -> None:
         dt = float(t.item())
     value = world * B * args.steps / dt
 
+    # the same region with the batch handed over from pinned host memory each step (reported beside `value`)
+    x_host = x.cpu().pin_memory()
+    for _ in range(5):
+        x.copy_(x_host, non_blocking=True)
+        enc.learn(x, sync=False, global_count=gcount)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x.copy_(x_host, non_blocking=True)
+        enc.learn(x, sync=False, global_count=gcount)
+    barrier()
+    dt_h2d = time.perf_counter() - t0
+
     # per-kernel HIP-event timing over an identical region (events on the launch stream)
     lib = _lib.load()
     lib.hhrl_prof_reset()
@@ -181,6 +215,12 @@ def main() -> None:
             achieved = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": achieved / PEAK_HBM_GBS, "traffic": None}
+        workload = "vae_train_b%d_n%d_g%d" % (B, N, g)
+        tr = pmc_traffic(workload, dom_name)
+        if tr is not None:
+            roof["traffic"] = tr["bytes"]
+            roof["traffic_unit"] = "bytes per launch"
+            roof["traffic_source"] = tr["source"]
         roof["avg_launch_us"] = 1e3 * dom["ms"] / max(dom["launches"], 1)
         roof["launches_per_step"] = dom["launches"] / prof_steps
         step_alg_tflops = vae_flops_per_lane(N, g) * B / (dt / args.steps) / 1e12
@@ -189,9 +229,10 @@ def main() -> None:
             "metric": "VAE train lane-samples/s", "value": value, "unit": "lane-samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "vae_train_b%d_n%d_g%d" % (B, N, g), "lanes_per_gpu": B, "cars_per_lane": N,
+            "config": {"workload": workload, "lanes_per_gpu": B, "cars_per_lane": N,
                        "latent": g, "global_batch": B * world, "parallelism": "dp%d" % world},
             "roofline": roof,
+            "value_with_h2d_per_step": world * B * args.steps / dt_h2d,
             "step_algorithmic_tflops": step_alg_tflops,
             "step_frac_of_fp32_matrix_peak": step_alg_tflops / PEAK_FP32_MATRIX_TFLOPS,
             "gpu_kernel_ms_per_step": gpu_ms_per_step,
