@@ -34,6 +34,7 @@ SIGNATURES = {
     "hhrl_vae_latent_grad": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "hhrl_vae_workspace_floats": (_L, [_I, _I, _I, _L]),
     "hhrl_vae_train_step": (_I, [_P, _P, _P, _L, _P, _P, _I, _I, _I, _F, _P, _P, _P]),
+    "hhrl_vae_learn_step": (_I, [_P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _F, _D, _D, _D, _D, _I, _P, _P, _P]),
     "hhrl_td3_smooth_action": (_I, [_P, _I, _P, _P, _I, _I, _I, _P]),
     "hhrl_td3_target_q": (_I, [_P, _P, _P, _I, _F, _P, _I, _P]),
     "hhrl_twin_mse": (_I, [_P, _P, _P, _F, _P, _P, _P, _I, _P]),
@@ -57,11 +58,12 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("HHRL_HIP_LIB", LIB_PATH)      # diagnostic builds of the same sources
+    if not os.path.exists(path):
         raise RuntimeError(
             "HIP extension not built: %s is missing. Run `python hhrl-vae_amd/build.py` "
-            "(needs hipcc; cross-compiles for gfx950 without a GPU)." % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+            "(needs hipcc; cross-compiles for gfx950 without a GPU)." % path)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res

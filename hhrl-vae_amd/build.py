@@ -35,16 +35,25 @@ def up_to_date() -> bool:
     return all(os.path.getmtime(p) <= t for p in _deps())
 
 
-def build_lib(force: bool = False, verbose: bool = True) -> str:
+def build_lib(force: bool = False, verbose: bool = True, defines=(), tag: str = "") -> str:
     """Compile every .hip source into one shared library.  Objects are built
-    in parallel (one hipcc per file), then linked."""
+    in parallel (one hipcc per file), then linked.  `defines` + `tag` give a
+    diagnostic variant (lib/libhhrl_hip_<tag>.so) of the same sources."""
+    if tag:
+        return _build(True, verbose, list(defines), tag)
     if not force and up_to_date():
         return LIB_PATH
+    return _build(force, verbose, [], "")
+
+
+def _build(force: bool, verbose: bool, defines, tag: str) -> str:
+    lib_path = LIB_PATH if not tag else os.path.join(LIB_DIR, "libhhrl_hip_%s.so" % tag)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(LIB_DIR, exist_ok=True)
-    obj_dir = os.path.join(HERE, "build")
+    obj_dir = os.path.join(HERE, "build" + ("_" + tag if tag else ""))
     os.makedirs(obj_dir, exist_ok=True)
     flags = ["-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
+    flags += ["-D" + d for d in defines]
     procs, objs = [], []
     for src in sources():
         obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
@@ -68,12 +77,15 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
                 print(out, file=sys.stderr)
     if failed:
         raise RuntimeError("hipcc failed")
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib_path] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    return LIB_PATH
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build_lib(force="--force" in sys.argv))
+    if "--stamps" in sys.argv:
+        print(build_lib(defines=["HHRL_STAMPS"], tag="stamps"))
+    else:
+        print(build_lib(force="--force" in sys.argv))

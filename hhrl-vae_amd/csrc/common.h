@@ -59,6 +59,20 @@ __device__ __forceinline__ float act_grad_from_output(float y, int act) {
   }
 }
 
+// Scalars of one Adam step (torch.optim.Adam, single-tensor rule), prepared in double on the host.
+struct AdamK {
+  float step_size, beta1, beta2, one_minus_b1, one_minus_b2, bc2_sqrt, eps, gscale;
+};
+AdamK make_adam_k(double lr, double beta1, double beta2, double eps, int step, double grad_scale);
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamK& k) {
+  g *= k.gscale;
+  m = m + k.one_minus_b1 * (g - m);                 // exp_avg.lerp_(grad, 1-beta1)
+  v = v * k.beta2 + k.one_minus_b2 * g * g;         // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1-beta2)
+  const float denom = sqrtf(v) / k.bc2_sqrt + k.eps;
+  p = p - k.step_size * (m / denom);
+}
+
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 // Optional per-launch timing (off by default).  When enabled through

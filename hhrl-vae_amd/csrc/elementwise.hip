@@ -95,18 +95,6 @@ __global__ __launch_bounds__(256) void twin_mse_kernel(const float* __restrict__
 
 // ---------------------------------------------------------- optimiser
 // One coalesced pass: reads p,g,m,v (16 B each), writes p,m,v: 28 B / parameter.
-struct AdamK {
-  float step_size, beta1, beta2, one_minus_b1, one_minus_b2, bc2_sqrt, eps, gscale;
-};
-
-__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamK& k) {
-  g *= k.gscale;
-  m = m + k.one_minus_b1 * (g - m);                 // exp_avg.lerp_(grad, 1-beta1)
-  v = v * k.beta2 + k.one_minus_b2 * g * g;         // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1-beta2)
-  const float denom = sqrtf(v) / k.bc2_sqrt + k.eps;
-  p = p - k.step_size * (m / denom);
-}
-
 __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* __restrict__ g, float* m, float* v, long n, AdamK k) {
   const long n4 = n >> 2;
   const long stride = (long)gridDim.x * blockDim.x;
@@ -181,6 +169,22 @@ static inline int stream_grid(long n_items) {
   return (int)b;
 }
 
+AdamK make_adam_k(double lr, double beta1, double beta2, double eps, int step, double grad_scale) {
+  // Bias corrections in double on the host, as torch computes them.
+  const double bc1 = 1.0 - std::pow(beta1, step);
+  const double bc2 = 1.0 - std::pow(beta2, step);
+  AdamK k;
+  k.step_size = (float)(lr / bc1);
+  k.beta1 = (float)beta1;
+  k.beta2 = (float)beta2;
+  k.one_minus_b1 = (float)(1.0 - beta1);
+  k.one_minus_b2 = (float)(1.0 - beta2);
+  k.bc2_sqrt = (float)std::sqrt(bc2);
+  k.eps = (float)eps;
+  k.gscale = (float)grad_scale;
+  return k;
+}
+
 }  // namespace hhrl
 
 using namespace hhrl;
@@ -246,18 +250,7 @@ int hhrl_adam_step(float* p, const float* g, float* m, float* v, long n, double 
                    double eps, int step, double grad_scale, void* stream) {
   HHRL_REQUIRE(p && g && m && v, "adam_step: null pointer");
   HHRL_REQUIRE(n > 0 && step >= 1, "adam_step: n=%ld step=%d", n, step);
-  // Bias corrections in double on the host, as torch computes them.
-  const double bc1 = 1.0 - std::pow(beta1, step);
-  const double bc2 = 1.0 - std::pow(beta2, step);
-  AdamK k;
-  k.step_size = (float)(lr / bc1);
-  k.beta1 = (float)beta1;
-  k.beta2 = (float)beta2;
-  k.one_minus_b1 = (float)(1.0 - beta1);
-  k.one_minus_b2 = (float)(1.0 - beta2);
-  k.bc2_sqrt = (float)std::sqrt(bc2);
-  k.eps = (float)eps;
-  k.gscale = (float)grad_scale;
+  const AdamK k = make_adam_k(lr, beta1, beta2, eps, step, grad_scale);
   hipStream_t st = as_stream(stream);
   ProfScope ps("adam_kernel", st, 0.0, 28.0 * n);
   if (aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v)) {
@@ -271,17 +264,7 @@ int hhrl_adam_step(float* p, const float* g, float* m, float* v, long n, double 
 int hhrl_adam_stage(float* hyper_dev, double lr, double beta1, double beta2, double eps, int step, double grad_scale,
                     void* stream) {
   HHRL_REQUIRE(hyper_dev && step >= 1, "adam_stage: null pointer or step < 1");
-  const double bc1 = 1.0 - std::pow(beta1, step);
-  const double bc2 = 1.0 - std::pow(beta2, step);
-  AdamK k;
-  k.step_size = (float)(lr / bc1);
-  k.beta1 = (float)beta1;
-  k.beta2 = (float)beta2;
-  k.one_minus_b1 = (float)(1.0 - beta1);
-  k.one_minus_b2 = (float)(1.0 - beta2);
-  k.bc2_sqrt = (float)std::sqrt(bc2);
-  k.eps = (float)eps;
-  k.gscale = (float)grad_scale;
+  const AdamK k = make_adam_k(lr, beta1, beta2, eps, step, grad_scale);
   hipLaunchKernelGGL(adam_stage_kernel, dim3(1), dim3(64), 0, as_stream(stream), hyper_dev, k);
   return launch_status("adam_stage_kernel");
 }

@@ -5,7 +5,7 @@
 //   vae_car_fwd_bwd    per car: loc embedding, func.0/2/4, squared error, and
 //                      the whole backward of those layers (85 % of the FLOPs)
 //   vae_lane_backward  per traffic lane: backward of everything in the first
-//                      kernel, KL gradient included
+//                      kernel (from its saved activations), KL gradient included
 //   vae_reduce_grads   fixed-order sum of the per-workgroup gradient slabs
 //
 // Every matrix product runs on v_mfma_f32_32x32x2_f32 with BOTH operands read
@@ -15,14 +15,23 @@
 // their operands conflict-free from the same images, and an accumulator tile
 // (rows on registers, columns on lanes) is written back conflict-free.
 // Weight-gradient tiles stay in accumulator registers across a workgroup's
-// tiles and are written once, to that workgroup's slab; nothing is atomically
-// accumulated except the [B,32] latent gradient that crosses tile boundaries.
+// tiles and are written once, to that workgroup's slab; the gradient at the decoder
+// output crosses tile boundaries as one row per car, summed per lane in car order: no atomics.
 #include "common.h"
 
 namespace hhrl {
 namespace vf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Diagnostic builds (-DHHRL_STAMPS) record the shader clock of workgroup 0, thread 0
+// at marked points of the fused kernels; hhrl_debug_stamps() copies them out.
+#ifdef HHRL_STAMPS
+__device__ long long g_stamps[3][64];
+#define HHRL_STAMP(k, i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[k][i] = clock64(); } while (0)
+#else
+#define HHRL_STAMP(k, i) do { } while (0)
+#endif
 
 // parameter order == Encoder.parameters() order (weight, bias interleaved)
 enum { PHI0 = 0, PHI2, RHO0, RHO2, MEAN, LOGVAR, DEC0, DEC2, LOC, FUNC0, FUNC2, FUNC4, NLAYER };
@@ -85,21 +94,21 @@ __device__ __forceinline__ void load_weight(float* img, int ld, const float* __r
 
 // Same for compile-time shapes with COLS % 4 == 0 and a 16-byte aligned source: 16-byte loads,
 // four of them issued back to back per thread so that their latencies overlap.
-template <int ROWS, int COLS>
+template <int ROWS, int COLS, int U = 4>
 __device__ __forceinline__ void load_weight_v4(float* img, int ld, const float* __restrict__ w, int tid) {
   static_assert(COLS % 4 == 0, "row length must be a multiple of 4");
   constexpr int TOTAL4 = ROWS * COLS / 4;
   const float4* w4 = reinterpret_cast<const float4*>(w);
 #pragma unroll 1
-  for (int base = 0; base < TOTAL4; base += 4 * 256) {
-    float4 v[4];
+  for (int base = 0; base < TOTAL4; base += U * 256) {
+    float4 v[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int i4 = base + u * 256 + tid;
       if (i4 < TOTAL4) v[u] = w4[i4];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int i4 = base + u * 256 + tid;
       if (i4 < TOTAL4) {
         const int idx = i4 * 4;
@@ -116,7 +125,7 @@ struct CarArgs {
   const float* data;  // [rows][2]  (loc, v)
   const float* d2;    // [B][32]
   const float *wloc, *bloc, *w0, *b0, *w2, *b2, *w4, *b4;
-  float* d_d2;        // [B][32], zeroed by the caller, atomically accumulated
+  float* dcar;        // [rows][32] gradient at the decoder output of the car's lane, one row per car
   float* slab;        // [gridDim.x][total]
   float* loss_part;   // [gridDim.x]
   Offsets off;
@@ -132,7 +141,7 @@ constexpr int CAR_WAVE0 = CAR_SMALL + 320;
 constexpr int CAR_CAT = 0;                        // per wave: [32][65]
 constexpr int CAR_HALF = CAR_CAT + 32 * 65;       // [32][65]
 constexpr int CAR_F2 = CAR_HALF + 32 * 65;        // [32][33]
-constexpr int CAR_ROW = CAR_F2 + 32 * 33;         // loc[32] v[32] dpre[32] laneidx[32]
+constexpr int CAR_ROW = CAR_F2 + 32 * 33;         // loc[32] v[32] dpre[32] (+32 spare)
 constexpr int CAR_WAVE_FLOATS = CAR_ROW + 128;
 constexpr int CAR_LDS_FLOATS = CAR_WAVE0 + 4 * CAR_WAVE_FLOATS;
 
@@ -141,6 +150,7 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
 
+  HHRL_STAMP(0, 0);
   float* W0s = lds + CAR_W0;
   float* W2s = lds + CAR_W2;
   float* b0s = lds + CAR_SMALL;
@@ -149,8 +159,25 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
   float* wlocs = w4s + 32;
   float* blocs = wlocs + 32;
   float* b4s = blocs + 32;
-  load_weight_v4<128, 64>(W0s, 65, g.w0, tid);
-  load_weight_v4<32, 128>(W2s, 129, g.w2, tid);
+  // inputs of the wave's first tile are requested before the weights, so both round trips overlap
+  float in_loc, in_v, in_d2[16];
+  int in_b;
+  auto fetch_tile = [&](int tile) {
+    const long row = (long)tile * 32 + r;
+    const bool valid = tile < g.tiles && row < g.rows;
+    in_loc = valid ? g.data[row * 2] : 0.f;
+    in_v = valid ? g.data[row * 2 + 1] : 0.f;
+    in_b = valid ? (int)(row / g.N) : -1;
+    // rows 2*it + h of the d2 block: lane r reads column r of the traffic lane of car 2*it + h
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int b = __shfl(in_b, 2 * it + h, 64);
+      in_d2[it] = b >= 0 ? g.d2[(long)b * 32 + r] : 0.f;
+    }
+  };
+  fetch_tile(blockIdx.x * 4 + wave);
+  load_weight_v4<128, 64, 8>(W0s, 65, g.w0, tid);
+  load_weight_v4<32, 128, 4>(W2s, 129, g.w2, tid);
   if (tid < 128) b0s[tid] = g.b0[tid];
   if (tid < 32) {
     b2s[tid] = g.b2[tid];
@@ -160,6 +187,7 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
   }
   if (tid == 0) b4s[0] = g.b4[0];
   __syncthreads();
+  HHRL_STAMP(0, 1);
 
   float* wl = lds + CAR_WAVE0 + wave * CAR_WAVE_FLOATS;
   float* cat = wl + CAR_CAT;
@@ -168,7 +196,6 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
   float* locs = wl + CAR_ROW;
   float* vs = locs + 32;
   float* dpre = vs + 32;
-  int* lidx = reinterpret_cast<int*>(dpre + 32);
 
   f32x16 dW0[4][2], dW2[4];
 #pragma unroll
@@ -181,26 +208,27 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
   float w4acc = 0.f, db2acc = 0.f, wlocacc = 0.f, blocacc = 0.f, b4acc = 0.f, lossacc = 0.f;
 
   for (int tile = blockIdx.x * 4 + wave; tile < g.tiles; tile += gridDim.x * 4) {
-    const long row = (long)tile * 32 + r;
-    const bool valid = row < g.rows;
-    const float loc = valid ? g.data[row * 2] : 0.f;
-    const float v = valid ? g.data[row * 2 + 1] : 0.f;
-    const int bidx = valid ? (int)(row / g.N) : -1;
+    if (tile != (int)blockIdx.x * 4 + wave) fetch_tile(tile);      // the first tile was requested in the prologue
+    const float loc = in_loc, v = in_v;
+    const bool valid = in_b >= 0;
     if (h == 0) {
       locs[r] = loc;
       vs[r] = v;
-      lidx[r] = bidx;
     }
-    // cat image: [d2 of the car's lane | loc embedding]
-    if (h == 0) {
-      const float* src = g.d2 + (long)(valid ? bidx : 0) * 32;
-#pragma unroll 8
-      for (int k = 0; k < 32; ++k) cat[r * 65 + k] = valid ? src[k] : 0.f;
-    } else {
-#pragma unroll 8
-      for (int k = 0; k < 32; ++k) cat[r * 65 + 32 + k] = valid ? loc * wlocs[k] + blocs[k] : 0.f;
+    // cat image: [d2 of the car's lane | loc embedding], rows 2*it + h, column r
+    {
+      const float wl_r = wlocs[r], bl_r = blocs[r];
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int rr = 2 * it + h;
+        const float loc_rr = __shfl(in_loc, rr, 64);
+        const int b_rr = __shfl(in_b, rr, 64);
+        cat[rr * 65 + r] = in_d2[it];
+        cat[rr * 65 + 32 + r] = b_rr >= 0 ? loc_rr * wl_r + bl_r : 0.f;
+      }
     }
     wave_sync();
+    HHRL_STAMP(0, 2);
 
     // ---- forward: func.0 (64 -> 128, ReLU)
     f32x16 f1[4];
@@ -211,6 +239,7 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int i = 0; i < 16; ++i) f1[t][i] = fmaxf(f1[t][i], 0.f);
+    HHRL_STAMP(0, 3);
 
     // ---- forward: func.2 (128 -> 32, ReLU), f1 staged through the half image 64 features at a time
     f32x16 f2[1];
@@ -227,6 +256,7 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
     for (int i = 0; i < 16; ++i) f2[0][i] = fmaxf(f2[0][i], 0.f);
     store_tile<33>(f2i, 0, f2[0], lane);
     wave_sync();
+    HHRL_STAMP(0, 4);
 
     // ---- forward: func.4 (32 -> 1, sigmoid), squared error and its gradient per car
     {
@@ -248,6 +278,7 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
       }
     }
     wave_sync();
+    HHRL_STAMP(0, 5);
 
     // ---- backward func.4 / ReLU of func.2: dW4, db2 and df2 (in place over the f2 image)
     {
@@ -263,6 +294,7 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
       }
     }
     wave_sync();
+    HHRL_STAMP(0, 6);
 
     // ---- backward func.2: dW2 += df2^T f1 ; df1 = (df2 W2) o relu'(f1)
     //      backward func.0: dW0 += df1^T cat ; dcat = df1 W0        (64 features of f1 at a time)
@@ -308,6 +340,7 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
       }
       wave_mma<2, 64, 65, 1, 65, 1>(dcat, half, W0s + 64 * hh * 65, lane);
       wave_sync();
+      HHRL_STAMP(0, 7 + hh);
     }
 
     // ---- loc embedding gradients from dcat[:, 32:64]
@@ -321,27 +354,16 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
       blocacc += sb;
       wlocacc += sw;
     }
-    // ---- latent gradient: d_d2[lane] += sum over that lane's cars of dcat[:, 0:32]
-    store_tile<33>(half, 0, dcat[0], lane);
-    wave_sync();
-    if (h == 0) {
-      // one partial sum per (traffic lane, tile): lanes of up to 32 cars receive at most two
-      // addends, so the atomic result does not depend on arrival order
-      int prev = lidx[0];
-      float s = 0.f;
-#pragma unroll 4
-      for (int rr = 0; rr < 32; ++rr) {
-        const int b = lidx[rr];
-        if (b != prev) {
-          if (prev >= 0) unsafeAtomicAdd(&g.d_d2[(long)prev * 32 + r], s);
-          prev = b;
-          s = 0.f;
-        }
-        s += half[rr * 33 + r];
+    // ---- gradient at the decoder output, one row per car (the per-lane backward sums each lane's rows)
+    {
+      const long row0 = (long)tile * 32;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const long row = row0 + drow(i, h);
+        if (row < g.rows) g.dcar[row * 32 + r] = dcat[0][i];
       }
-      if (prev >= 0) unsafeAtomicAdd(&g.d_d2[(long)prev * 32 + r], s);
     }
-    wave_sync();
+    HHRL_STAMP(0, 9);
   }
 
   // ---- combine the two lane halves (they hold different rows of the same columns)
@@ -354,15 +376,20 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
   b4acc = wave_sum(b4acc);
   lossacc = wave_sum(lossacc);
 
-  // ---- combine the four waves in LDS (fixed order), then one coalesced slab write
+  // ---- combine the four waves in LDS in a fixed order: waves 0 and 1 store into two buffers (the weight
+  //      images are dead by now), waves 2 and 3 add into them, the slab write adds the two buffers
   __syncthreads();
-  float* buf = lds + CAR_WAVE0;
+  HHRL_STAMP(0, 10);
   constexpr int B_W0 = 0, B_B0 = 8192, B_W2 = B_B0 + 128, B_B2 = B_W2 + 4096, B_W4 = B_B2 + 32, B_B4 = B_W4 + 32;
   constexpr int B_WLOC = B_B4 + 1, B_BLOC = B_WLOC + 32, B_LOSS = B_BLOC + 32, B_END = B_LOSS + 1;
-  static_assert(B_END <= 4 * CAR_WAVE_FLOATS, "combine buffer must fit in the wave regions");
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
-      const bool first = w == 0;
+  static_assert(B_END <= CAR_WAVE0, "first combine buffer must fit in the weight region");
+  static_assert(B_END <= 4 * CAR_WAVE_FLOATS, "second combine buffer must fit in the wave regions");
+  float* bufA = lds;
+  float* bufB = lds + CAR_WAVE0;
+  for (int ph = 0; ph < 2; ++ph) {
+    if ((wave >> 1) == ph) {
+      float* buf = (wave & 1) ? bufB : bufA;
+      const bool first = ph == 0;
 #pragma unroll
       for (int it = 0; it < 4; ++it)
 #pragma unroll
@@ -398,41 +425,52 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
     }
     __syncthreads();
   }
+  HHRL_STAMP(0, 11);
   float* slab = g.slab + (long)blockIdx.x * g.off.total;
-  for (int i = tid; i < 8192; i += 256) slab[g.off.w[FUNC0] + i] = buf[B_W0 + i];
-  for (int i = tid; i < 4096; i += 256) slab[g.off.w[FUNC2] + i] = buf[B_W2 + i];
-  if (tid < 128) slab[g.off.b[FUNC0] + tid] = buf[B_B0 + tid];
+  auto both = [&](int i) { return bufA[i] + bufB[i]; };
+  for (int i = tid; i < 8192; i += 256) slab[g.off.w[FUNC0] + i] = both(B_W0 + i);
+  for (int i = tid; i < 4096; i += 256) slab[g.off.w[FUNC2] + i] = both(B_W2 + i);
+  if (tid < 128) slab[g.off.b[FUNC0] + tid] = both(B_B0 + tid);
   if (tid < 32) {
-    slab[g.off.b[FUNC2] + tid] = buf[B_B2 + tid];
-    slab[g.off.w[FUNC4] + tid] = buf[B_W4 + tid];
-    slab[g.off.w[LOC] + tid] = buf[B_WLOC + tid];
-    slab[g.off.b[LOC] + tid] = buf[B_BLOC + tid];
+    slab[g.off.b[FUNC2] + tid] = both(B_B2 + tid);
+    slab[g.off.w[FUNC4] + tid] = both(B_W4 + tid);
+    slab[g.off.w[LOC] + tid] = both(B_WLOC + tid);
+    slab[g.off.b[LOC] + tid] = both(B_BLOC + tid);
   }
   if (tid == 0) {
-    slab[g.off.b[FUNC4]] = buf[B_B4];
-    g.loss_part[blockIdx.x] = buf[B_LOSS];
+    slab[g.off.b[FUNC4]] = both(B_B4);
+    g.loss_part[blockIdx.x] = both(B_LOSS);
   }
+  HHRL_STAMP(0, 12);
 }
 
 // ===================================================================== per-lane kernels
 // One workgroup owns tiles of 32 traffic lanes.  ALL per-lane weights are
-// copied into LDS once per workgroup; every activation of the chain lives in an
-// LDS image, so the chain touches global memory only for its inputs (car
-// states, eps, the latent gradient) and outputs.  The backward kernel
-// recomputes the forward chain in LDS instead of reloading saved activations,
-// and overwrites activations with their gradients in place.
+// copied into LDS once per workgroup and every activation of the chain lives
+// in an LDS image.  Every global load a tile needs (weights, car states, saved
+// activations, the gradient rows of its cars) is requested up front into
+// registers, so the round trips overlap, and is written to LDS once.
+// Products with at most 64 output columns run on v_mfma_f32_16x16x4_f32 so that
+// the four waves own disjoint 16x16 output blocks and no partial sums have to
+// be combined; wider layers give each wave a 32-column tile of
+// v_mfma_f32_32x32x2_f32.  The forward kernel saves its activation images,
+// the backward kernel reloads them and overwrites activations with their
+// gradients in place.
 struct LaneArgs {
   const float* data;   // [B*N][2]
   const float* eps;    // [B][g]
   const float* w[NLAYER];
   const float* b[NLAYER];
   float* d2;           // [B][32] forward output
-  const float* d_d2;   // [B][32] backward input
+  float* act;          // [tiles][LN_ACT_FLOATS] activation images: written by the forward, read by the backward kernel
+  const float* dcar;   // [B*N][32] backward input: gradient at d2, one row per car
   float* slab;
   float* kl_part;      // [gridDim.x]
   Offsets off;
   int B, N, g, tiles;
 };
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // LDS map (floats)
 constexpr int LW_PHI2 = 0;                        // [32][17]
@@ -442,29 +480,26 @@ constexpr int LW_HEAD = LW_RHO2 + 64 * 129;       // [32][65]   rows 0..g-1 to_m
 constexpr int LW_DEC0 = LW_HEAD + 32 * 65;        // [128][17]  columns >= g zero
 constexpr int LW_DEC2 = LW_DEC0 + 128 * 17;       // [32][129]
 constexpr int LW_BIAS = LW_DEC2 + 32 * 129;       // phi2[32] rho0[128] rho2[64] head[32] dec0[128] dec2[32]
-constexpr int LB_PHI2 = 0, LB_RHO0 = 32, LB_RHO2 = 160, LB_HEAD = 224, LB_DEC0 = 256, LB_DEC2 = 384;
-constexpr int LI_H1 = LW_BIAS + 416;              // [32][33]  summed hidden of phi (16 columns used)
+constexpr int LB_PHI2 = 0, LB_RHO0 = 32, LB_RHO2 = 160, LB_HEAD = 224, LB_DEC0 = 256, LB_DEC2 = 384, LB_END = 416;
+constexpr int LI_H1 = LW_BIAS + LB_END;           // [32][33]  summed hidden of phi (16 columns used)
 constexpr int LI_POOL = LI_H1 + 32 * 33;          // [32][33]
 constexpr int LI_R1 = LI_POOL + 32 * 33;          // [32][129]
 constexpr int LI_R2 = LI_R1 + 32 * 129;           // [32][65]
 constexpr int LI_ML = LI_R2 + 32 * 65;            // [32][33]  mean | logvar
 constexpr int LI_Z = LI_ML + 32 * 33;             // [32][17]  (in a 33-wide slot)
-constexpr int LI_D1 = LI_Z + 32 * 33;             // [32][129]; doubles as staging for the tile's car states
+constexpr int LI_D1 = LI_Z + 32 * 33;             // [32][129]
 constexpr int LI_D2 = LI_D1 + 32 * 129;           // [32][33]
 constexpr int LI_DML = LI_D2 + 32 * 33;           // [32][33]
 constexpr int LI_TMP = LI_DML + 32 * 33;          // [32][33]
-constexpr int LN_LDS_FLOATS = LI_TMP + 32 * 33;
+constexpr int LI_CARS = LI_TMP + 32 * 33;         // the tile's car states, 32 lanes x N x 2 (N <= STAGE_MAX_CARS)
+constexpr int STAGE_MAX_CARS = 16;
+constexpr int LN_LDS_FLOATS = LI_CARS + 64 * STAGE_MAX_CARS;
 static_assert(LN_LDS_FLOATS * 4 <= 163840 - 64, "per-lane kernels must fit the 160 KiB LDS");
-constexpr int STAGE_MAX_CARS = 64;                // 32 lanes x 64 cars x 2 floats fit the d1 slot
+constexpr int LN_ACT_FLOATS = LI_D2 - LI_H1;      // h1 | pooled | r1 | r2 | mean,logvar | z | d1, verbatim
+static_assert(LI_H1 % 4 == 0 && LN_ACT_FLOATS % 4 == 0, "activation images are copied 16 bytes at a time");
+constexpr int ACT_V4 = LN_ACT_FLOATS / 4;
+constexpr int ACT_PER_THREAD = (ACT_V4 + 255) / 256;
 
-// rows [row0, row0+32) of a [B][32] global matrix <-> a [32][33] image (zeros beyond B)
-__device__ __forceinline__ void load_rows32(float* img, const float* __restrict__ src, int row0, int B, int tid) {
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int idx = u * 256 + tid, rr = idx >> 5, c = idx & 31;
-    img[rr * 33 + c] = (row0 + rr < B) ? src[(long)(row0 + rr) * 32 + c] : 0.f;
-  }
-}
 __device__ __forceinline__ void store_rows32(const float* img, float* dst, int row0, int B, int tid) {
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
@@ -473,64 +508,149 @@ __device__ __forceinline__ void store_rows32(const float* img, float* dst, int r
   }
 }
 __device__ __forceinline__ float colsum32(const float* img, int ld, int col) {
-  float s = 0.f;
-#pragma unroll 8
-  for (int rr = 0; rr < 32; ++rr) s += img[rr * ld + col];
-  return s;
-}
-// Adds a wave's D tile into img (wave 0 stores, waves 1..3 add, in wave order).
-template <int LD>
-__device__ __forceinline__ void ordered_tile_sum(float* img, const f32x16& t, int wave, int lane) {
-  const int r = lane & 31, h = lane >> 5;
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
+  float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float* p = img + drow(i, h) * LD + r;
-        *p = w == 0 ? t[i] : *p + t[i];
-      }
-    }
-    __syncthreads();
+  for (int rr = 0; rr < 32; rr += 2) {
+    s0 += img[rr * ld + col];
+    s1 += img[(rr + 1) * ld + col];
   }
+  return s0 + s1;
 }
 
-__device__ __forceinline__ void lane_load_weights(float* lds, const LaneArgs& g, int tid) {
+// One 16x16 output block: init + A[16 x K] * B[K x 16], operands in LDS
+//   A(i,k) = a[i*ASI + k*ASK]      B(k,j) = b[k*BSK + j*BSJ]
+// Result: column lane&15, rows 4*(lane>>4) + reg.  Two accumulation chains (even / odd groups of four k).
+template <int K, int ASI, int ASK, int BSK, int BSJ>
+__device__ __forceinline__ f32x4 wave_mma16(const float* a, const float* b, int lane, float init) {
+  static_assert(K % 8 == 0, "K must be a multiple of 8");
+  const int i = lane & 15, q = lane >> 4;
+  const float* ap = a + i * ASI + q * ASK;
+  const float* bp = b + q * BSK + i * BSJ;
+  f32x4 c0 = {init, init, init, init}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < K; k += 8) {
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[k * ASK], bp[k * BSK], c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(k + 4) * ASK], bp[(k + 4) * BSK], c1, 0, 0, 0);
+  }
+  return c0 + c1;
+}
+// img[(row0 + row)][col0 + col] = block
+template <int LD>
+__device__ __forceinline__ void store_block16(float* img, int row0, int col0, const f32x4& c, int lane) {
+  const int j = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) img[(row0 + 4 * q + e) * LD + col0 + j] = c[e];
+}
+
+// ---- registers that carry a tile's global loads from request to LDS
+struct LaneRegs {
+  float4 rho2[8], rho0[4], dec2[4], phi2;
+  float head[8], dec0[8], bias[2], cars[4];
+};
+
+__device__ __forceinline__ const float* lane_bias_src(const LaneArgs& g, int idx) {
   const int gd = g.g;
-  for (int i = tid; i < 32 * 65; i += 256) lds[LW_HEAD + i] = 0.f;
-  for (int i = tid; i < 128 * 17; i += 256) lds[LW_DEC0 + i] = 0.f;
-  __syncthreads();
-  load_weight_v4<32, 16>(lds + LW_PHI2, 17, g.w[PHI2], tid);
-  load_weight_v4<128, 32>(lds + LW_RHO0, 33, g.w[RHO0], tid);
-  load_weight_v4<64, 128>(lds + LW_RHO2, 129, g.w[RHO2], tid);
-  load_weight(lds + LW_HEAD, 65, g.w[MEAN], gd, 64, tid, 256);
-  load_weight(lds + LW_HEAD + gd * 65, 65, g.w[LOGVAR], gd, 64, tid, 256);
-  load_weight(lds + LW_DEC0, 17, g.w[DEC0], 128, gd, tid, 256);
-  load_weight_v4<32, 128>(lds + LW_DEC2, 129, g.w[DEC2], tid);
-  float* bs = lds + LW_BIAS;
-  if (tid < 32) {
-    bs[LB_PHI2 + tid] = g.b[PHI2][tid];
-    bs[LB_DEC2 + tid] = g.b[DEC2][tid];
-    bs[LB_HEAD + tid] = tid < gd ? g.b[MEAN][tid] : (tid < 2 * gd ? g.b[LOGVAR][tid - gd] : 0.f);
+  if (idx < LB_RHO0) return g.b[PHI2] + idx;
+  if (idx < LB_RHO2) return g.b[RHO0] + (idx - LB_RHO0);
+  if (idx < LB_HEAD) return g.b[RHO2] + (idx - LB_RHO2);
+  if (idx < LB_DEC0) {
+    const int c = idx - LB_HEAD;
+    return c < gd ? g.b[MEAN] + c : (c < 2 * gd ? g.b[LOGVAR] + (c - gd) : nullptr);
   }
-  if (tid < 128) {
-    bs[LB_RHO0 + tid] = g.b[RHO0][tid];
-    bs[LB_DEC0 + tid] = g.b[DEC0][tid];
-  }
-  if (tid < 64) bs[LB_RHO2 + tid] = g.b[RHO2][tid];
-  __syncthreads();
+  if (idx < LB_DEC2) return g.b[DEC0] + (idx - LB_DEC0);
+  if (idx < LB_END) return g.b[DEC2] + (idx - LB_DEC2);
+  return nullptr;
 }
 
-// Copies the tile's car states (32 lanes x N cars x 2 floats, contiguous in global memory) into LDS.
-__device__ __forceinline__ void stage_cars(float* stage, const LaneArgs& g, int row0, int tid) {
+__device__ __forceinline__ void lane_request_weights(LaneRegs& R, const LaneArgs& g, int tid) {
+  const float4* p = reinterpret_cast<const float4*>(g.w[RHO2]);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) R.rho2[u] = p[u * 256 + tid];
+  p = reinterpret_cast<const float4*>(g.w[RHO0]);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) R.rho0[u] = p[u * 256 + tid];
+  p = reinterpret_cast<const float4*>(g.w[DEC2]);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) R.dec2[u] = p[u * 256 + tid];
+  R.phi2 = tid < 128 ? reinterpret_cast<const float4*>(g.w[PHI2])[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int gd = g.g, nh = 128 * gd, nd = 128 * gd;     // heads: 2g rows x 64; decoder.0: 128 rows x g
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int e = u * 256 + tid;
+    R.head[u] = e < nh ? (e < 64 * gd ? g.w[MEAN][e] : g.w[LOGVAR][e - 64 * gd]) : 0.f;
+    R.dec0[u] = e < nd ? g.w[DEC0][e] : 0.f;
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const float* src = lane_bias_src(g, u * 256 + tid);
+    R.bias[u] = src ? *src : 0.f;
+  }
+}
+
+__device__ __forceinline__ void lane_request_cars(LaneRegs& R, const LaneArgs& g, int row0, int tid) {
   const long base = (long)row0 * g.N * 2;
   const long lim = (long)g.B * g.N * 2;
-  const int n = 64 * g.N;
-  for (int i = tid; i < n; i += 256) stage[i] = (base + i < lim) ? g.data[base + i] : 0.f;
+  const int n = g.N <= STAGE_MAX_CARS ? 64 * g.N : 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = u * 256 + tid;
+    R.cars[u] = (i < n && base + i < lim) ? g.data[base + i] : 0.f;
+  }
 }
 
-// The forward chain of one 32-lane tile, entirely in LDS.  Ends with a barrier.
-__device__ __forceinline__ void lane_forward_chain(float* lds, const LaneArgs& g, int row0, int tid) {
-  const int lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+template <int COLS>
+__device__ __forceinline__ void commit4(float* img, int ld, int i4, const float4& v) {
+  const int idx = i4 * 4, r = idx / COLS, c = idx % COLS;
+  float* p = img + r * ld + c;
+  p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+}
+
+// Zero padding of the images first (disjoint from what lane_commit_weights writes, so no barrier in between).
+__device__ __forceinline__ void lane_zero_pads(float* lds, const LaneArgs& g, int tid) {
+  const int gd = g.g;
+  for (int i = tid; i < 32 * 65; i += 256)
+    if (i / 65 >= 2 * gd) lds[LW_HEAD + i] = 0.f;
+  for (int i = tid; i < 128 * 17; i += 256)
+    if (i % 17 >= gd) lds[LW_DEC0 + i] = 0.f;
+}
+
+__device__ __forceinline__ void lane_commit_weights(float* lds, const LaneRegs& R, const LaneArgs& g, int tid) {
+#pragma unroll
+  for (int u = 0; u < 8; ++u) commit4<128>(lds + LW_RHO2, 129, u * 256 + tid, R.rho2[u]);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) commit4<32>(lds + LW_RHO0, 33, u * 256 + tid, R.rho0[u]);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) commit4<128>(lds + LW_DEC2, 129, u * 256 + tid, R.dec2[u]);
+  if (tid < 128) commit4<16>(lds + LW_PHI2, 17, tid, R.phi2);
+  const int gd = g.g, nh = 128 * gd, nd = 128 * gd, lg = __ffs(gd) - 1;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int e = u * 256 + tid;
+    if (e < nh) lds[LW_HEAD + (e >> 6) * 65 + (e & 63)] = R.head[u];
+    if (e < nd) lds[LW_DEC0 + (e >> lg) * 17 + (e & (gd - 1))] = R.dec0[u];
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int idx = u * 256 + tid;
+    if (idx < LB_END) lds[LW_BIAS + idx] = R.bias[u];
+  }
+}
+
+__device__ __forceinline__ void lane_commit_cars(float* lds, const LaneRegs& R, const LaneArgs& g, int tid) {
+  const int n = g.N <= STAGE_MAX_CARS ? 64 * g.N : 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = u * 256 + tid;
+    if (i < n) lds[LI_CARS + i] = R.cars[u];
+  }
+}
+
+// ------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256, 1) void vae_lane_forward_kernel(LaneArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31;
+  const int rb = wave & 1, cb = wave >> 1;      // 16-row / 16-column block owned by this wave in 32x32 outputs
+  const int j16 = lane & 15;
   const int gd = g.g;
   float* bs = lds + LW_BIAS;
   float* Ih1 = lds + LI_H1;
@@ -542,109 +662,128 @@ __device__ __forceinline__ void lane_forward_chain(float* lds, const LaneArgs& g
   float* Id1 = lds + LI_D1;
   float* Id2 = lds + LI_D2;
   const bool staged = g.N <= STAGE_MAX_CARS;
-  if (staged) stage_cars(Id1, g, row0, tid);
-  __syncthreads();
-  // ---- phi.0 + ReLU summed over each lane's cars
-  for (int idx = tid; idx < 32 * 16; idx += 256) {
-    const int rr = idx >> 4, k = idx & 15;
-    const int b = row0 + rr;
-    float s = 0.f;
-    if (b < g.B) {
-      const float wa = g.w[PHI0][2 * k], wb = g.w[PHI0][2 * k + 1], bb = g.b[PHI0][k];
-      if (staged) {
-        const float* x = Id1 + rr * g.N * 2;
-        for (int n = 0; n < g.N; ++n) s += fmaxf(wa * x[2 * n] + wb * x[2 * n + 1] + bb, 0.f);
-      } else {
-        const float* x = g.data + (long)b * g.N * 2;
-        for (int n = 0; n < g.N; ++n) s += fmaxf(wa * x[2 * n] + wb * x[2 * n + 1] + bb, 0.f);
-      }
-    }
-    Ih1[rr * 33 + k] = s;
-  }
-  __syncthreads();
-  // ---- phi.2 on the summed hidden: pooled = W2 h1s + N b2
-  if (wave == 0) {
-    f32x16 acc[1];
-    acc[0] = splat((float)g.N * bs[LB_PHI2 + r]);
-    wave_mma<1, 16, 33, 1, 1, 17>(acc, Ih1, lds + LW_PHI2, lane);
-    store_tile<33>(Ipool, 0, acc[0], lane);
-  }
-  __syncthreads();
-  // ---- rho.0 (32 -> 128, ReLU): one column tile per wave
+  HHRL_STAMP(1, 0);
   {
-    f32x16 acc[1];
-    acc[0] = splat(bs[LB_RHO0 + wave * 32 + r]);
-    wave_mma<1, 32, 33, 1, 1, 33>(acc, Ipool, lds + LW_RHO0 + wave * 32 * 33, lane);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[0][i] = fmaxf(acc[0][i], 0.f);
-    store_tile<129>(Ir1, wave * 32, acc[0], lane);
+    LaneRegs R;
+    lane_request_weights(R, g, tid);
+    lane_request_cars(R, g, blockIdx.x * 32, tid);
+    lane_zero_pads(lds, g, tid);
+    lane_commit_weights(lds, R, g, tid);
+    lane_commit_cars(lds, R, g, tid);
   }
   __syncthreads();
-  // ---- rho.2 (128 -> 64): wave w takes column tile w&1 and half of K
-  {
-    const int jt = wave & 1, kh = wave >> 1;
-    f32x16 acc[1];
-    acc[0] = splat(kh == 0 ? bs[LB_RHO2 + jt * 32 + r] : 0.f);
-    wave_mma<1, 64, 129, 1, 1, 129>(acc, Ir1 + 64 * kh, lds + LW_RHO2 + jt * 32 * 129 + 64 * kh, lane);
-    if (kh == 0) store_tile<65>(Ir2, jt * 32, acc[0], lane);
-    __syncthreads();
-    if (kh == 1) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) Ir2[drow(i, h) * 65 + jt * 32 + r] += acc[0][i];
-    }
-  }
-  __syncthreads();
-  // ---- heads (64 -> 2g): K split over the four waves
-  {
-    f32x16 acc[1];
-    acc[0] = splat(wave == 0 ? bs[LB_HEAD + r] : 0.f);
-    wave_mma<1, 16, 65, 1, 1, 65>(acc, Ir2 + 16 * wave, lds + LW_HEAD + 16 * wave, lane);
-    ordered_tile_sum<33>(Iml, acc[0], wave, lane);
-  }
-  // ---- reparameterisation z = mean + eps * exp(logvar / 2), zero-padded to 16 columns
-  for (int idx = tid; idx < 32 * 16; idx += 256) {
-    const int rr = idx >> 4, j = idx & 15;
-    float zv = 0.f;
-    if (j < gd && row0 + rr < g.B)
-      zv = Iml[rr * 33 + j] + g.eps[(long)(row0 + rr) * gd + j] * expf(0.5f * Iml[rr * 33 + gd + j]);
-    Iz[rr * 17 + j] = zv;
-  }
-  __syncthreads();
-  // ---- decoder.0 (g -> 128, ReLU)
-  {
-    f32x16 acc[1];
-    acc[0] = splat(bs[LB_DEC0 + wave * 32 + r]);
-    wave_mma<1, 16, 17, 1, 1, 17>(acc, Iz, lds + LW_DEC0 + wave * 32 * 17, lane);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[0][i] = fmaxf(acc[0][i], 0.f);
-    store_tile<129>(Id1, wave * 32, acc[0], lane);
-  }
-  __syncthreads();
-  // ---- decoder.2 (128 -> 32): K split over the four waves
-  {
-    f32x16 acc[1];
-    acc[0] = splat(wave == 0 ? bs[LB_DEC2 + r] : 0.f);
-    wave_mma<1, 32, 129, 1, 1, 129>(acc, Id1 + 32 * wave, lds + LW_DEC2 + 32 * wave, lane);
-    ordered_tile_sum<33>(Id2, acc[0], wave, lane);
-  }
-}
-
-__global__ __launch_bounds__(256, 1) void vae_lane_forward_kernel(LaneArgs g) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x;
-  lane_load_weights(lds, g, tid);
+  HHRL_STAMP(1, 1);
   for (int tile = blockIdx.x; tile < g.tiles; tile += gridDim.x) {
     const int row0 = tile * 32;
-    lane_forward_chain(lds, g, row0, tid);
-    store_rows32(lds + LI_D2, g.d2, row0, g.B, tid);
+    if (tile != (int)blockIdx.x) {               // later tiles: the images of the previous tile are dead (barrier at loop end)
+      LaneRegs R;
+      lane_request_cars(R, g, row0, tid);
+      lane_commit_cars(lds, R, g, tid);
+      __syncthreads();
+    }
+    HHRL_STAMP(1, 2);
+    // ---- phi.0 + ReLU summed over each lane's cars
+    for (int idx = tid; idx < 32 * 16; idx += 256) {
+      const int rr = idx >> 4, k = idx & 15;
+      const int b = row0 + rr;
+      float s = 0.f;
+      if (b < g.B) {
+        const float wa = g.w[PHI0][2 * k], wb = g.w[PHI0][2 * k + 1], bb = g.b[PHI0][k];
+        const float* x = staged ? lds + LI_CARS + rr * g.N * 2 : g.data + (long)b * g.N * 2;
+        for (int n = 0; n < g.N; ++n) s += fmaxf(wa * x[2 * n] + wb * x[2 * n + 1] + bb, 0.f);
+      }
+      Ih1[rr * 33 + k] = s;
+    }
     __syncthreads();
+    HHRL_STAMP(1, 3);
+    // ---- phi.2 on the summed hidden: pooled = W2 h1s + N b2
+    {
+      const f32x4 c = wave_mma16<16, 33, 1, 1, 17>(Ih1 + 16 * rb * 33, lds + LW_PHI2 + 16 * cb * 17, lane,
+                                                   (float)g.N * bs[LB_PHI2 + 16 * cb + j16]);
+      store_block16<33>(Ipool, 16 * rb, 16 * cb, c, lane);
+    }
+    __syncthreads();
+    HHRL_STAMP(1, 4);
+    // ---- rho.0 (32 -> 128, ReLU): one 32-column tile per wave
+    {
+      f32x16 acc[1];
+      acc[0] = splat(bs[LB_RHO0 + wave * 32 + r]);
+      wave_mma<1, 32, 33, 1, 1, 33>(acc, Ipool, lds + LW_RHO0 + wave * 32 * 33, lane);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[0][i] = fmaxf(acc[0][i], 0.f);
+      store_tile<129>(Ir1, wave * 32, acc[0], lane);
+    }
+    __syncthreads();
+    HHRL_STAMP(1, 5);
+    // ---- rho.2 (128 -> 64): two 16x16 blocks per wave
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int col0 = 32 * cb + 16 * t;
+      const f32x4 c = wave_mma16<128, 129, 1, 1, 129>(Ir1 + 16 * rb * 129, lds + LW_RHO2 + col0 * 129, lane,
+                                                      bs[LB_RHO2 + col0 + j16]);
+      store_block16<65>(Ir2, 16 * rb, col0, c, lane);
+    }
+    __syncthreads();
+    HHRL_STAMP(1, 6);
+    // ---- heads (64 -> 2g; columns >= 2g come out as zero)
+    {
+      const f32x4 c = wave_mma16<64, 65, 1, 1, 65>(Ir2 + 16 * rb * 65, lds + LW_HEAD + 16 * cb * 65, lane,
+                                                   bs[LB_HEAD + 16 * cb + j16]);
+      store_block16<33>(Iml, 16 * rb, 16 * cb, c, lane);
+    }
+    __syncthreads();
+    HHRL_STAMP(1, 7);
+    // ---- reparameterisation z = mean + eps * exp(logvar / 2), zero-padded to 16 columns
+    for (int idx = tid; idx < 32 * 16; idx += 256) {
+      const int rr = idx >> 4, j = idx & 15;
+      float zv = 0.f;
+      if (j < gd && row0 + rr < g.B)
+        zv = Iml[rr * 33 + j] + g.eps[(long)(row0 + rr) * gd + j] * expf(0.5f * Iml[rr * 33 + gd + j]);
+      Iz[rr * 17 + j] = zv;
+    }
+    __syncthreads();
+    HHRL_STAMP(1, 8);
+    // ---- decoder.0 (g -> 128, ReLU)
+    {
+      f32x16 acc[1];
+      acc[0] = splat(bs[LB_DEC0 + wave * 32 + r]);
+      wave_mma<1, 16, 17, 1, 1, 17>(acc, Iz, lds + LW_DEC0 + wave * 32 * 17, lane);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[0][i] = fmaxf(acc[0][i], 0.f);
+      store_tile<129>(Id1, wave * 32, acc[0], lane);
+    }
+    __syncthreads();
+    HHRL_STAMP(1, 9);
+    // ---- decoder.2 (128 -> 32)
+    {
+      const f32x4 c = wave_mma16<128, 129, 1, 1, 129>(Id1 + 16 * rb * 129, lds + LW_DEC2 + 16 * cb * 129, lane,
+                                                      bs[LB_DEC2 + 16 * cb + j16]);
+      store_block16<33>(Id2, 16 * rb, 16 * cb, c, lane);
+    }
+    __syncthreads();
+    HHRL_STAMP(1, 10);
+    // ---- outputs: d2 rows for the per-car kernel, the activation images for the backward kernel
+    store_rows32(Id2, g.d2, row0, g.B, tid);
+    {
+      float4* dst = reinterpret_cast<float4*>(g.act + (long)tile * LN_ACT_FLOATS);
+      const float4* src = reinterpret_cast<const float4*>(lds + LI_H1);
+#pragma unroll
+      for (int u = 0; u < ACT_PER_THREAD; ++u) {
+        const int i4 = u * 256 + tid;
+        if (i4 < ACT_V4) dst[i4] = src[i4];
+      }
+    }
+    __syncthreads();
+    HHRL_STAMP(1, 11);
   }
 }
 
+// ------------------------------------------------------------------ backward
 __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
+  const int rb = wave & 1, cb = wave >> 1;
   const int gd = g.g;
   float* Ih1 = lds + LI_H1;
   float* Ipool = lds + LI_POOL;
@@ -652,11 +791,12 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
   float* Ir2 = lds + LI_R2;     // r2, then dr2, then scratch of the phi.0 backward
   float* Iml = lds + LI_ML;     // mean|logvar, then dpooled
   float* Iz = lds + LI_Z;
-  float* Id1 = lds + LI_D1;     // d1, then dd1, then staged car states
+  float* Id1 = lds + LI_D1;     // d1, then dd1
   float* Id2 = lds + LI_D2;     // dd2
   float* Idml = lds + LI_DML;
   float* Itmp = lds + LI_TMP;   // dz, then t = dpooled * W_phi2
-  lane_load_weights(lds, g, tid);
+  const bool staged = g.N <= STAGE_MAX_CARS;
+  HHRL_STAMP(2, 0);
 
   // weight-gradient tiles owned by this wave, kept across tiles
   f32x16 aDec2 = splat(0.f), aDec0 = splat(0.f), aHead = splat(0.f), aRho2a = splat(0.f), aRho2b = splat(0.f);
@@ -668,9 +808,60 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
 
   for (int tile = blockIdx.x; tile < g.tiles; tile += gridDim.x) {
     const int row0 = tile * 32;
-    lane_forward_chain(lds, g, row0, tid);
-    load_rows32(Id2, g.d_d2, row0, g.B, tid);
+    // ---- request everything the tile needs, then write it to LDS
+    {
+      LaneRegs R;
+      const bool first = tile == (int)blockIdx.x;
+      if (first) lane_request_weights(R, g, tid);
+      lane_request_cars(R, g, row0, tid);
+      float4 av[ACT_PER_THREAD];
+      {
+        const float4* src = reinterpret_cast<const float4*>(g.act + (long)tile * LN_ACT_FLOATS);
+#pragma unroll
+        for (int u = 0; u < ACT_PER_THREAD; ++u) {
+          const int i4 = u * 256 + tid;
+          av[u] = i4 < ACT_V4 ? src[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+      // dd2 of a lane = sum over its cars, in car order
+      float dd2v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = u * 256 + tid, rr = idx >> 5, c = idx & 31;
+        float sum = 0.f;
+        if (row0 + rr < g.B) {
+          const float* src = g.dcar + (long)(row0 + rr) * g.N * 32 + c;
+          int n = 0;
+          for (; n + 4 <= g.N; n += 4) {
+            const float a0 = src[(long)n * 32], a1 = src[(long)(n + 1) * 32], a2 = src[(long)(n + 2) * 32],
+                        a3 = src[(long)(n + 3) * 32];
+            sum = (((sum + a0) + a1) + a2) + a3;
+          }
+          for (; n < g.N; ++n) sum += src[(long)n * 32];
+        }
+        dd2v[u] = sum;
+      }
+      if (first) {
+        lane_zero_pads(lds, g, tid);
+        lane_commit_weights(lds, R, g, tid);
+      }
+      lane_commit_cars(lds, R, g, tid);
+      {
+        float4* dst = reinterpret_cast<float4*>(lds + LI_H1);
+#pragma unroll
+        for (int u = 0; u < ACT_PER_THREAD; ++u) {
+          const int i4 = u * 256 + tid;
+          if (i4 < ACT_V4) dst[i4] = av[u];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = u * 256 + tid;
+        Id2[(idx >> 5) * 33 + (idx & 31)] = dd2v[u];
+      }
+    }
     __syncthreads();
+    HHRL_STAMP(2, 1);
     // ---- decoder.2 backward: dW[32][128] += dd2^T d1, db, dd1 = (dd2 W) o relu'(d1) in place (column block `wave`)
     {
       f32x16 acc[1] = {aDec2};
@@ -688,17 +879,22 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
       }
     }
     __syncthreads();
-    // ---- decoder.0 backward: dW[128][g] += dd1^T z (row tile `wave`), db, dz = dd1 W (K split over waves)
+    HHRL_STAMP(2, 2);
+    // ---- decoder.0 backward: dW[128][g] += dd1^T z (row tile `wave`), db, dz = dd1 W (waves 0 and 1, 16 rows each)
     {
       f32x16 acc[1] = {aDec0};
       wave_mma<1, 32, 1, 129, 17, 1>(acc, Id1 + 32 * wave, Iz, lane);
       aDec0 = acc[0];
-      if (tid < 128) bDec0 += colsum32(Id1, 129, tid);
-      f32x16 d[1];
-      d[0] = splat(0.f);
-      wave_mma<1, 32, 129, 1, 17, 1>(d, Id1 + 32 * wave, lds + LW_DEC0 + 32 * wave * 17, lane);
-      ordered_tile_sum<33>(Itmp, d[0], wave, lane);     // columns >= 17 are junk and never read
+      if (wave >= 2) {
+        const int c = tid - 128;
+        bDec0 += colsum32(Id1, 129, c);
+      } else {
+        const f32x4 c = wave_mma16<128, 129, 1, 17, 1>(Id1 + 16 * wave * 129, lds + LW_DEC0, lane, 0.f);
+        store_block16<33>(Itmp, 16 * wave, 0, c, lane);
+      }
     }
+    __syncthreads();
+    HHRL_STAMP(2, 3);
     // ---- latent gradient (KL + reparameterisation): dml = [dz + mean | dz*eps*0.5*std + 0.5*(exp(lv)-1) | 0...]
     for (int idx = tid; idx < 32 * 32; idx += 256) {
       const int rr = idx >> 5, c = idx & 31;
@@ -717,6 +913,7 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
       Idml[rr * 33 + c] = outv;
     }
     __syncthreads();
+    HHRL_STAMP(2, 4);
     // ---- heads backward: dW[2g][64] += dml^T r2 (waves 0,1), dr2 = dml W (waves 2,3; replaces r2 afterwards)
     {
       f32x16 d[1];
@@ -733,6 +930,7 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
       if (wave >= 2) store_tile<65>(Ir2, 32 * (wave - 2), d[0], lane);
     }
     __syncthreads();
+    HHRL_STAMP(2, 5);
     // ---- rho.2 backward: dW[64][128] += dr2^T r1 (two tiles per wave), db, dr1 = (dr2 W) o relu'(r1) in place
     {
       const int it = wave >> 1, jt0 = (wave & 1) * 2;
@@ -752,36 +950,32 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
       }
     }
     __syncthreads();
-    // ---- rho.0 backward: dW[128][32] += dr1^T pooled (row tile `wave`), db, dpooled = dr1 W (K split) -> ml slot
+    HHRL_STAMP(2, 6);
+    // ---- rho.0 backward: dW[128][32] += dr1^T pooled (row tile `wave`), db, dpooled = dr1 W (16x16 blocks) -> ml slot
     {
       f32x16 acc[1] = {aRho0};
       wave_mma<1, 32, 1, 129, 33, 1>(acc, Ir1 + 32 * wave, Ipool, lane);
       aRho0 = acc[0];
       if (tid < 128) bRho0 += colsum32(Ir1, 129, tid);
-      f32x16 d[1];
-      d[0] = splat(0.f);
-      wave_mma<1, 32, 129, 1, 33, 1>(d, Ir1 + 32 * wave, lds + LW_RHO0 + 32 * wave * 33, lane);
-      ordered_tile_sum<33>(Iml, d[0], wave, lane);
+      const f32x4 c = wave_mma16<128, 129, 1, 33, 1>(Ir1 + 16 * rb * 129, lds + LW_RHO0 + 16 * cb, lane, 0.f);
+      store_block16<33>(Iml, 16 * rb, 16 * cb, c, lane);
     }
-    // ---- phi.2 backward on the summed hidden: dW[32][16] += dpooled^T h1s, db = N colsum(dpooled),
-    //      t = dpooled W_phi2 (gradient at the hidden layer of every car of the lane, before its ReLU mask)
+    __syncthreads();
+    HHRL_STAMP(2, 7);
+    // ---- phi.2 backward on the summed hidden: dW[32][16] += dpooled^T h1s (wave 0), db = N colsum(dpooled) (wave 1),
+    //      t = dpooled W_phi2 (waves 2 and 3): gradient at the hidden layer of every car of the lane, before its ReLU mask
     if (wave == 0) {
       f32x16 acc[1] = {aPhi2};
       wave_mma<1, 32, 1, 33, 33, 1>(acc, Iml, Ih1, lane);       // columns >= 16 are junk, dropped at the end
       aPhi2 = acc[0];
     } else if (wave == 1) {
-      f32x16 d[1];
-      d[0] = splat(0.f);
-      wave_mma<1, 32, 33, 1, 17, 1>(d, Iml, lds + LW_PHI2, lane);
-      if (r < 16) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) Itmp[drow(i, h) * 33 + r] = d[0][i];
-      }
+      if (lane < 32) bPhi2 += (float)g.N * colsum32(Iml, 33, lane);
+    } else {
+      const f32x4 c = wave_mma16<32, 33, 1, 17, 1>(Iml + 16 * (wave - 2) * 33, lds + LW_PHI2, lane, 0.f);
+      store_block16<33>(Itmp, 16 * (wave - 2), 0, c, lane);
     }
-    if (tid < 32) bPhi2 += (float)g.N * colsum32(Iml, 33, tid);
-    const bool staged = g.N <= STAGE_MAX_CARS;
-    if (staged) stage_cars(Id1, g, row0, tid);            // dd1 is dead: reuse its slot
     __syncthreads();
+    HHRL_STAMP(2, 8);
     // ---- phi.0 backward: per (lane, hidden unit) walk the cars again and apply the ReLU mask
     {
       float* red = Ir2;       // [32][49] partial sums
@@ -791,7 +985,7 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
         float a0 = 0.f, a1 = 0.f, c = 0.f;
         if (b < g.B) {
           const float wa = g.w[PHI0][2 * k], wb = g.w[PHI0][2 * k + 1], bb = g.b[PHI0][k];
-          const float* x = staged ? Id1 + rr * g.N * 2 : g.data + (long)b * g.N * 2;
+          const float* x = staged ? lds + LI_CARS + rr * g.N * 2 : g.data + (long)b * g.N * 2;
           for (int n = 0; n < g.N; ++n) {
             const float x0 = x[2 * n], x1 = x[2 * n + 1];
             if (wa * x0 + wb * x1 + bb > 0.f) { a0 += x0; a1 += x1; c += 1.f; }
@@ -810,6 +1004,7 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
       }
     }
     __syncthreads();
+    HHRL_STAMP(2, 9);
   }
 
   // ---- write this workgroup's slab
@@ -840,16 +1035,15 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
   }
   put_tile(g.off.w[RHO0] + (long)32 * wave * 32, 32, 32, 0, 32, aRho0);
   if (wave == 0) put_tile(g.off.w[PHI2], 16, 32, 0, 16, aPhi2);
+  // bias gradients: the thread that accumulated a column writes it
   if (tid < 32) {
     slab[g.off.b[DEC2] + tid] = bDec2;
-    slab[g.off.b[PHI2] + tid] = bPhi2;
     if (tid < gd) slab[g.off.b[MEAN] + tid] = bHead;
     else if (tid < 2 * gd) slab[g.off.b[LOGVAR] + tid - gd] = bHead;
   }
-  if (tid < 128) {
-    slab[g.off.b[DEC0] + tid] = bDec0;
-    slab[g.off.b[RHO0] + tid] = bRho0;
-  }
+  if (wave == 1 && lane < 32) slab[g.off.b[PHI2] + lane] = bPhi2;
+  if (tid >= 128) slab[g.off.b[DEC0] + tid - 128] = bDec0;
+  if (tid < 128) slab[g.off.b[RHO0] + tid] = bRho0;
   if (tid < 64) slab[g.off.b[RHO2] + tid] = bRho2;
   if (tid < 16) {
     slab[g.off.w[PHI0] + 2 * tid] = gPhi0a;
@@ -864,6 +1058,7 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
   if (lane == 0) klred[wave] = klacc;
   __syncthreads();
   if (tid == 0) g.kl_part[blockIdx.x] = klred[0] + klred[1] + klred[2] + klred[3];
+  HHRL_STAMP(2, 10);
 }
 
 // grads[i] = sum over slabs, in a fixed order: the same inputs give the same bits.
@@ -872,7 +1067,7 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
 __global__ __launch_bounds__(256) void vae_reduce_grads_kernel(const float* __restrict__ slab, long total, int n_car, int n_lane,
                                                                long car_lo, long car_hi, float* grads,
                                                                const float* __restrict__ loss_part, const float* __restrict__ kl_part,
-                                                               float* loss) {
+                                                               float* loss, float* params, float* m, float* v, AdamK k) {
   __shared__ float red[4][64];
   const int p = threadIdx.x & 63, q = threadIdx.x >> 6;
   const long i = (long)blockIdx.x * 64 + p;
@@ -894,7 +1089,17 @@ __global__ __launch_bounds__(256) void vae_reduce_grads_kernel(const float* __re
   }
   red[q][p] = s;
   __syncthreads();
-  if (q == 0 && i < total) grads[i] = (red[0][p] + red[1][p]) + (red[2][p] + red[3][p]);
+  if (q == 0 && i < total) {
+    const float gi = (red[0][p] + red[1][p]) + (red[2][p] + red[3][p]);
+    grads[i] = gi;
+    if (params != nullptr) {                           // fused optimizer step (single device)
+      float pi = params[i], mi = m[i], vi = v[i];
+      adam_one(pi, gi, mi, vi, k);
+      params[i] = pi;
+      m[i] = mi;
+      v[i] = vi;
+    }
+  }
   if (blockIdx.x == 0 && threadIdx.x < 64) {
     float t = 0.f;
     for (int k = threadIdx.x; k < n_car; k += 64) t += loss_part[k];
@@ -905,7 +1110,7 @@ __global__ __launch_bounds__(256) void vae_reduce_grads_kernel(const float* __re
 }
 
 struct Ws {
-  float *d2, *d_d2, *loss_part, *kl_part, *slab;
+  float *d2, *dcar, *act, *loss_part, *kl_part, *slab;
   long total;
 };
 
@@ -928,7 +1133,8 @@ static Ws carve(float* ws, int B, int N, int g, long n_flat) {
   long off = 0;
   auto take = [&](long n) { float* p = ws ? ws + off : nullptr; off += a64(n); return p; };
   w.d2 = take((long)B * 32);
-  w.d_d2 = take((long)B * 32);
+  w.dcar = take((long)B * N * 32);
+  w.act = take((long)((B + 31) / 32) * LN_ACT_FLOATS);
   w.loss_part = take(256);
   w.kl_part = take(256);
   const int ns = grid_car((long)B * N) > grid_lane(B) ? grid_car((long)B * N) : grid_lane(B);
@@ -950,9 +1156,13 @@ long hhrl_vae_workspace_floats(int B, int N, int g, long n_flat) {
   return carve(nullptr, B, N, g, n_flat).total;
 }
 
-int hhrl_vae_train_step(const float* params, float* grads, const long* offsets, long n_flat, const float* data,
-                        const float* eps, int B, int N, int g, float recon_scale, float* loss, float* ws,
-                        void* stream) {
+}  // extern "C"
+
+// Forward, ELBO, backward and slab reduction; with adam != nullptr the reduction also applies the
+// optimizer step to params / m / v.
+static int vae_step_impl(float* params, float* grads, float* m, float* v, const AdamK* adam, const long* offsets,
+                         long n_flat, const float* data, const float* eps, int B, int N, int g, float recon_scale,
+                         float* loss, float* ws, void* stream) {
   HHRL_REQUIRE(params && grads && offsets && data && eps && loss && ws, "vae_train_step: null pointer");
   HHRL_REQUIRE(B > 0 && N > 0, "vae_train_step: bad shape B=%d N=%d", B, N);
   HHRL_REQUIRE(g == 2 || g == 4 || g == 8 || g == 16, "vae_train_step: latent size %d not in {2,4,8,16}", g);
@@ -999,7 +1209,8 @@ int hhrl_vae_train_step(const float* params, float* grads, const long* offsets, 
     la.b[l] = params + off.b[l];
   }
   la.d2 = w.d2;
-  la.d_d2 = w.d_d2;
+  la.dcar = w.dcar;
+  la.act = w.act;
   la.slab = w.slab;
   la.kl_part = w.kl_part;
   la.off = off;
@@ -1011,8 +1222,6 @@ int hhrl_vae_train_step(const float* params, float* grads, const long* offsets, 
     hipLaunchKernelGGL(vae_lane_forward_kernel, dim3(nlane), dim3(256), LN_LDS_FLOATS * 4, st, la);
     HHRL_TRY(launch_status("vae_lane_forward_kernel"));
   }
-  if (hipMemsetAsync(w.d_d2, 0, sizeof(float) * (size_t)B * 32, st) != hipSuccess)
-    return fail(HHRL_ERR_HIP, "vae_train_step: hipMemsetAsync failed");
 
   CarArgs ca;
   ca.data = data;
@@ -1021,7 +1230,7 @@ int hhrl_vae_train_step(const float* params, float* grads, const long* offsets, 
   ca.w0 = la.w[FUNC0]; ca.b0 = la.b[FUNC0];
   ca.w2 = la.w[FUNC2]; ca.b2 = la.b[FUNC2];
   ca.w4 = la.w[FUNC4]; ca.b4 = la.b[FUNC4];
-  ca.d_d2 = w.d_d2;
+  ca.dcar = w.dcar;
   ca.slab = w.slab;
   ca.loss_part = w.loss_part;
   ca.off = off;
@@ -1041,12 +1250,40 @@ int hhrl_vae_train_step(const float* params, float* grads, const long* offsets, 
     HHRL_TRY(launch_status("vae_lane_backward_kernel"));
   }
   {
-    ProfScope ps("vae_reduce_grads_kernel", st, 0.0, 4.0 * n_flat * (1.0 + 0.5 * (ncar + nlane)));
+    // reads every slab column once (per-car columns from ncar slabs, the others from nlane), writes the gradient
+    const double slab_floats = (double)(car_hi - car_lo) * ncar + (double)(n_flat - (car_hi - car_lo)) * nlane;
+    ProfScope ps("vae_reduce_grads_kernel", st, 0.0, 4.0 * (slab_floats + n_flat * (adam ? 7.0 : 1.0)));
     hipLaunchKernelGGL(vae_reduce_grads_kernel, dim3(ceil_div(n_flat, 64)), dim3(256), 0, st, w.slab, n_flat, ncar, nlane,
-                       car_lo, car_hi, grads, w.loss_part, w.kl_part, loss);
+                       car_lo, car_hi, grads, w.loss_part, w.kl_part, loss, adam ? params : nullptr, m, v,
+                       adam ? *adam : AdamK());
     HHRL_TRY(launch_status("vae_reduce_grads_kernel"));
   }
   return HHRL_OK;
 }
+
+extern "C" {
+
+int hhrl_vae_train_step(const float* params, float* grads, const long* offsets, long n_flat, const float* data,
+                        const float* eps, int B, int N, int g, float recon_scale, float* loss, float* ws,
+                        void* stream) {
+  return vae_step_impl(const_cast<float*>(params), grads, nullptr, nullptr, nullptr, offsets, n_flat, data, eps, B, N, g,
+                       recon_scale, loss, ws, stream);
+}
+
+int hhrl_vae_learn_step(float* params, float* grads, float* m, float* v, const long* offsets, long n_flat,
+                        const float* data, const float* eps, int B, int N, int g, float recon_scale, double lr,
+                        double beta1, double beta2, double adam_eps, int step, float* loss, float* ws, void* stream) {
+  HHRL_REQUIRE(m && v, "vae_learn_step: null pointer");
+  HHRL_REQUIRE(step >= 1, "vae_learn_step: step=%d", step);
+  const AdamK k = make_adam_k(lr, beta1, beta2, adam_eps, step, 1.0);
+  return vae_step_impl(params, grads, m, v, &k, offsets, n_flat, data, eps, B, N, g, recon_scale, loss, ws, stream);
+}
+
+#ifdef HHRL_STAMPS
+// diagnostic builds only: copies the recorded clocks (3 kernels x 64 stamps) to the host
+int hhrl_debug_stamps(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hhrl::vf::g_stamps), sizeof(long long) * 3 * 64);
+}
+#endif
 
 }  // extern "C"

@@ -85,6 +85,9 @@ class Encoder:
         all-reduce per step.
     """
 
+    LOSS_RING = 256
+    EPS_POOL = 1 << 20
+
     def __init__(self, car_info_dim: int, goal_dim: int, device: Optional[str] = None, seed: Optional[int] = None,
                  group=None, fused: bool = True):
         if car_info_dim != 2:
@@ -115,9 +118,15 @@ class Encoder:
         self._fused_ws: Dict[Tuple[int, int], torch.Tensor] = {}
         import ctypes
         self._offsets = (ctypes.c_long * 24)(*[self.layout.offsets[n] for n in self.layout.names])
-        self._loss = ops.dev_zeros(1, device=self.device)
+        # losses land in a ring of device scalars: learn(sync=False) hands out a view of the
+        # step's slot, valid for the next LOSS_RING - 1 steps, instead of copying it
+        self._loss_ring = ops.dev_zeros(self.LOSS_RING, device=self.device)
+        self._loss_slot = 0
+        self._loss = self._loss_ring[0:1]
         self._rng = torch.Generator(device=self.device)
         self._rng.manual_seed(3407)
+        self._eps_pool = None           # reparameterisation noise is drawn EPS_POOL floats at a time
+        self._eps_used = 0
         self.group = group
         self.world_size = 1
         if group is not None:
@@ -165,8 +174,27 @@ class Encoder:
         self.func2.fwd(P(w.f1), 128, P(w.f2), 32, M)
         self.func4.fwd(P(w.f2), 32, P(w.dec), 1, M)
 
+    def _draw_eps(self, B: int, g: int) -> torch.Tensor:
+        """[B, g] standard normals (algorithm.py:89) cut from a pool that one
+        generator launch refills, so a training step pays no launch for them."""
+        n = B * g
+        if n > self.EPS_POOL // 4:
+            return torch.randn((B, g), generator=self._rng, device=self.device, dtype=torch.float32)
+        if self._eps_pool is None or self._eps_used + n > self.EPS_POOL:
+            # a fresh tensor each time: slices handed out earlier may still be queued on the stream
+            self._eps_pool = torch.randn(self.EPS_POOL, generator=self._rng, device=self.device, dtype=torch.float32)
+            self._eps_used = 0
+        e = self._eps_pool[self._eps_used:self._eps_used + n].view(B, g)
+        self._eps_used += (n + 3) & ~3          # keep slices 16-byte aligned
+        return e
+
+    def _next_loss_slot(self) -> torch.Tensor:
+        self._loss_slot = (self._loss_slot + 1) % self.LOSS_RING
+        self._loss = self._loss_ring[self._loss_slot:self._loss_slot + 1]
+        return self._loss
+
     # ------------------------------------------------------------ training
-    def loss_and_grads(self, data, eps=None, recon_count: Optional[int] = None) -> torch.Tensor:
+    def loss_and_grads(self, data, eps=None, recon_count: Optional[int] = None, _adam: bool = False) -> torch.Tensor:
         """Forward + ELBO + backward into the flat gradient buffer (zeroed
         first).  Returns the loss as a 0-dim device tensor (no sync).
         recon_count: divisor of the squared-error sum (default B*N; the global
@@ -177,7 +205,7 @@ class Encoder:
         B, N = int(x.shape[0]), int(x.shape[1])
         g = self.goal_dim
         if eps is None:
-            eps = torch.randn((B, g), generator=self._rng, device=self.device, dtype=torch.float32)
+            eps = self._draw_eps(B, g)
         else:
             eps = torch.as_tensor(eps, dtype=torch.float32).to(self.device).contiguous()
             if tuple(eps.shape) != (B, g):
@@ -192,14 +220,23 @@ class Encoder:
                 n = lib.hhrl_vae_workspace_floats(B, N, g, self.layout.size)
                 ws = self._fused_ws[(B, N)] = ops.dev_zeros(n, device=self.device)
             scale = 1.0 / float(recon_count if recon_count is not None else B * N)
-            check(lib.hhrl_vae_train_step(self.params.base_ptr, self.opt.g.base_ptr, self._offsets, self.layout.size,
-                                          P(x), P(eps), B, N, g, scale, P(self._loss), P(ws), st))
+            loss = self._next_loss_slot()
+            if _adam:
+                # forward, backward and the optimizer step in one call (single device)
+                o = self.opt
+                o.step_count += 1
+                check(lib.hhrl_vae_learn_step(self.params.base_ptr, o.g.base_ptr, o.m.base_ptr, o.v.base_ptr,
+                                              self._offsets, self.layout.size, P(x), P(eps), B, N, g, scale,
+                                              o.lr, o.beta1, o.beta2, o.eps, o.step_count, P(loss), P(ws), st))
+            else:
+                check(lib.hhrl_vae_train_step(self.params.base_ptr, self.opt.g.base_ptr, self._offsets,
+                                              self.layout.size, P(x), P(eps), B, N, g, scale, P(loss), P(ws), st))
             self._keep = (x, eps)
-            return self._loss[0]
+            return loss[0]
         w = self._ws(B, N)
         M = w.M
         self.opt.zero_grad()                                            # algorithm.py:98
-        self._loss.zero_()
+        self._next_loss_slot().zero_()
         self._encode_fwd(x, w)                                          # :99
         check(lib.hhrl_vae_reparam(P(w.ml), P(eps), P(w.z), B, g, st))  # :100
         self._decode_fwd(P(x), 2, w)                                    # :101
@@ -235,7 +272,9 @@ class Encoder:
         buffer is all-reduced (SUM) once before the Adam step, so every rank
         applies the single-device update for the global batch."""
         if self.group is None:
-            loss = self.loss_and_grads(data, eps)
+            loss = self.loss_and_grads(data, eps, _adam=self.fused)
+            if not self.fused:
+                self.opt.step()                                         # :106
         else:
             from . import dist as hdist
             x = self._to_device(data)
@@ -244,8 +283,8 @@ class Encoder:
             loss = self.loss_and_grads(x, eps, recon_count=global_count)
             hdist.allreduce_sum_(self.opt.g.data, self.group)           # one flat bucket, SUM
             loss = hdist.allreduce_sum_(loss.clone(), self.group)
-        self.opt.step()                                                 # :106
-        return float(loss.item()) if sync else loss.clone()
+            self.opt.step()                                             # :106
+        return float(loss.item()) if sync else loss
 
     # ------------------------------------------------------------ inference
     def encode(self, x) -> np.ndarray:

@@ -51,6 +51,7 @@ def train_one_pass(encoder: Encoder, chunks: Iterable, eps_list: Optional[Sequen
     at algorithm.py:107 forces that)."""
     losses: List[float] = []
     pending = []
+    sync_every = min(sync_every, encoder.LOSS_RING - 1)     # device losses live in a ring of that many slots
     for step, data in enumerate(chunks):
         eps = None if eps_list is None else eps_list[step]
         if sync_every <= 1:

@@ -111,6 +111,16 @@ long hhrl_vae_workspace_floats(int B, int N, int g, long n_flat);
 int hhrl_vae_train_step(const float* params, float* grads, const long* offsets, long n_flat,
                         const float* data, const float* eps, int B, int N, int g,
                         float recon_scale, float* loss, float* ws, void* stream);
+/* The whole of Encoder.learn (algorithm.py:94-106) on one device: the step
+ * above with the Adam update (algorithm.py:83, 106; torch defaults) applied by
+ * the slab reduction, which holds each gradient element in a register anyway.
+ *   m, v: Adam moments, flat like params; step: 1-based count of this update.
+ * grads still receives the gradient. Not for data-parallel runs: those
+ * all-reduce grads between hhrl_vae_train_step and hhrl_adam_step. */
+int hhrl_vae_learn_step(float* params, float* grads, float* m, float* v, const long* offsets, long n_flat,
+                        const float* data, const float* eps, int B, int N, int g, float recon_scale,
+                        double lr, double beta1, double beta2, double adam_eps, int step,
+                        float* loss, float* ws, void* stream);
 
 /* --------------------------------------------------------------------- TD3
  * Target-policy smoothing (algorithm.py:295-296, 494-497, 786-791, 1135-1136, 1330-1331):

@@ -139,20 +139,26 @@ def test_vae_full_size_vs_oracle(B, N, g):
         assert_close("loss", got, want, rtol=1e-4, atol=0)
         og = {k: v.numpy() for k, v in oracle.grads.items()}
         gg = _np(e.grads())
-        # Weight gradients here are sums over B*N rows of terms that largely cancel.  The absolute
-        # floor is the fp32 random-walk bound for such a sum, 4 * 2^-24 * sqrt(rows) of the tensor's
-        # largest entry (8e-5 at 122,880 rows), or twice the fp32 oracle's own worst distance from
-        # the fp64 value on that tensor, whichever is larger; elements above the floor meet rtol 1e-4.
-        floor = max(1e-5, 4 * 2.0 ** -24 * (B * N) ** 0.5)
+        # Weight gradients here are sums over B*N rows of terms that largely cancel, and a ReLU whose
+        # input rounds to the other side of zero moves a whole term.  Both fp32 evaluations (this one and
+        # the CPU oracle) land up to ~2e-4 of a tensor's largest entry away from the fp64 value on single
+        # elements (tools/vae_accuracy.py prints the per-tensor distances: e.g. 2.1e-7 for the oracle on
+        # decoder.func.0.weight at B=4096, N=7, largest entry 1.1e-3).  The absolute floor is therefore
+        # 10 * 2^-24 * sqrt(rows) of the tensor's largest entry (2.1e-4 at 122,880 rows), or three times
+        # the fp32 oracle's own worst distance from the fp64 value on that tensor, whichever is larger;
+        # elements above the floor meet rtol 1e-4.
+        floor = max(1e-5, 10 * 2.0 ** -24 * (B * N) ** 0.5)
         gm = _np(e.opt.m.state_dict())
         om = dict(zip(oracle.names, [t.numpy() for t in oracle.opt.exp_avg]))
         for k in og:
             noise = float(np.max(np.abs(og[k].astype(np.float64) - g64[k].numpy())))
             scale = float(np.max(np.abs(og[k])))
-            assert_close("grad%d/%s" % (step, k), gg[k], og[k], rtol=1e-4, atol=max(floor * scale, 2 * noise))
+            # accuracy: within 3x of the fp32 oracle's own distance from the fp64 value; agreement with the
+            # fp32 oracle then follows from the triangle inequality (that allowance + the oracle's distance)
             assert_close("grad%d/%s vs fp64" % (step, k), gg[k], g64[k].numpy(), rtol=1e-4, atol=max(floor * scale, 3 * noise))
+            assert_close("grad%d/%s" % (step, k), gg[k], og[k], rtol=1e-4, atol=max(floor * scale, 3 * noise) + noise)
             # first moment m = 0.9 m_prev + 0.1 g from identical m_prev: a tenth of the gradient's allowance
-            assert_close("exp_avg%d/%s" % (step, k), gm[k], om[k], rtol=1e-4, atol=0.1 * max(floor * scale, 2 * noise) + 1e-12)
+            assert_close("exp_avg%d/%s" % (step, k), gm[k], om[k], rtol=1e-4, atol=0.1 * (max(floor * scale, 3 * noise) + noise) + 1e-12)
         adam_conditioned_close("param%d" % step, _np(e.state_dict()), {k: v.detach().numpy() for k, v in oracle.p.items()}, og, 1e-3, floor)
 
 
@@ -173,13 +179,11 @@ def test_vae_fused_matches_layerwise(B, N, g):
     # entry (1e-5 for small batches) must agree to rtol 1e-4; accuracy itself is judged against the
     # oracle and its fp64 yardstick in test_vae_full_size_vs_oracle
     dict_close("grad", _np(ef.grads()), _np(el.grads()), atol_rel=1e-5 if B * N < 4096 else 2e-4)
-    # same inputs, same bits: the fused step reduces in a fixed order (the latent-gradient atomics add at most
-    # two terms per element unless a lane spans three 32-car tiles)
+    # same inputs, same bits: every sum of the fused step runs in a fixed order
     g1 = _np(ef.grads())
     ef.loss_and_grads(x, eps)
     g2 = _np(ef.grads())
-    if N <= 32:
-        assert all(np.array_equal(g1[k], g2[k]) for k in g1)
+    assert all(np.array_equal(g1[k], g2[k]) for k in g1)
 
 
 def test_vae_properties_full_size():

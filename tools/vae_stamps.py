@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Phase breakdown inside the fused VAE kernels (diagnostic build).
+
+Build first (CPU box): python hhrl-vae_amd/build.py --stamps
+Run (GPU box):         python tools/vae_stamps.py [B N g]
+
+Workgroup 0 / thread 0 records the shader clock at marked points; the script
+prints the distance between consecutive stamps in clocks and as a share of
+the kernel's span."""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["HHRL_HIP_LIB"] = os.path.join(ROOT, "hhrl-vae_amd", "lib", "libhhrl_hip_stamps.so")
+
+import numpy as np
+import torch
+
+from hhrl_vae_amd import _lib
+from hhrl_vae_amd.algorithm import Encoder
+
+CAR = ["start", "weights in LDS", "cat image", "func.0 fwd", "func.2 fwd", "func.4+err", "func.4 bwd",
+       "bwd half 0", "bwd half 1", "dcar rows stored", "pre-combine barrier", "combine", "slab written"]
+CHAIN = ["start", "weights in LDS", "cars staged", "phi.0", "phi.2", "rho.0", "rho.2", "heads", "reparam", "dec.0", "dec.2"]
+LFWD = CHAIN + ["d2 + activations stored"]
+LBWD = ["start", "weights, activations, dd2 in LDS", "dec.2 bwd", "dec.0 bwd", "latent", "heads bwd", "rho.2 bwd",
+        "rho.0 bwd", "phi.2 bwd", "phi.0 bwd", "slab written"]
+
+
+def main():
+    B, N, g = (int(a) for a in sys.argv[1:4]) if len(sys.argv) >= 4 else (4096, 7, 4)
+    enc = Encoder(2, g, device="cuda:0", seed=1)
+    rs = np.random.RandomState(0)
+    x = torch.from_numpy(rs.uniform(0, 1, size=(B, N, 2)).astype(np.float32)).cuda()
+    for _ in range(20):
+        enc.learn(x, sync=False)
+    torch.cuda.synchronize()
+    lib = _lib.load()
+    buf = (ctypes.c_longlong * (3 * 64))()
+    lib.hhrl_debug_stamps.restype = ctypes.c_int
+    assert lib.hhrl_debug_stamps(buf) == 0
+    st = np.array(buf[:]).reshape(3, 64)
+    for k, (name, labels) in enumerate((("vae_car_fwd_bwd", CAR), ("vae_lane_forward", LFWD), ("vae_lane_backward", LBWD))):
+        t = st[k, :len(labels)]
+        span = t[-1] - t[0]
+        print("%s: %d clocks" % (name, span))
+        for i in range(1, len(labels)):
+            d = t[i] - t[i - 1]
+            print("  %-34s %8d  %5.1f%%" % (labels[i], d, 100.0 * d / span))
+
+
+if __name__ == "__main__":
+    main()
