@@ -16,8 +16,10 @@
 // (rows on registers, columns on lanes) is written back conflict-free.
 // Weight-gradient tiles stay in accumulator registers across a workgroup's
 // tiles and are written once, to that workgroup's slab; the gradient at the decoder
-// output crosses tile boundaries as one row per car, summed per lane in car order: no atomics.
+// output crosses tile boundaries as one row per (car tile, traffic lane), summed in tile order: no atomics.
 #include "common.h"
+
+#include <type_traits>
 
 namespace hhrl {
 namespace vf {
@@ -92,31 +94,39 @@ __device__ __forceinline__ void load_weight(float* img, int ld, const float* __r
   }
 }
 
-// Same for compile-time shapes with COLS % 4 == 0 and a 16-byte aligned source: 16-byte loads,
-// four of them issued back to back per thread so that their latencies overlap.
-template <int ROWS, int COLS, int U = 4>
-__device__ __forceinline__ void load_weight_v4(float* img, int ld, const float* __restrict__ w, int tid) {
-  static_assert(COLS % 4 == 0, "row length must be a multiple of 4");
-  constexpr int TOTAL4 = ROWS * COLS / 4;
-  const float4* w4 = reinterpret_cast<const float4*>(w);
-#pragma unroll 1
-  for (int base = 0; base < TOTAL4; base += U * 256) {
-    float4 v[U];
+// Weight matrices [ROWS][COLS] (row-major, 16-byte aligned, COLS % 32 == 0) travel as float4 per thread.
+// Thread -> element map: a group of 32 threads takes a block of 4 rows x 32 columns, 8 threads per row.
+// Global reads stay in 128-byte runs, and with an image row stride of 1 mod 32 the four 4-byte LDS
+// writes of a float4 land in 32 different banks across the group.
+template <int ROWS, int COLS>
+struct W4Map {
+  static_assert(COLS % 32 == 0 && ROWS % 4 == 0 && ((ROWS / 4) * (COLS / 32)) % 8 == 0, "unsupported weight shape");
+  static constexpr int CB = COLS / 32, STEPS = (ROWS / 4) * CB / 8;
+  __device__ __forceinline__ static void pos(int tid, int u, int& row, int& col) {
+    const int blk = u * 8 + (tid >> 5), br = blk / CB, bc = blk % CB;
+    row = 4 * br + ((tid & 31) >> 3);
+    col = 32 * bc + 4 * (tid & 7);
+  }
+};
+template <int ROWS, int COLS, int STEPS>
+__device__ __forceinline__ void request_w4(float4 (&v)[STEPS], const float* __restrict__ w, int tid) {
+  static_assert(STEPS == W4Map<ROWS, COLS>::STEPS, "register array does not match the weight shape");
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i4 = base + u * 256 + tid;
-      if (i4 < TOTAL4) v[u] = w4[i4];
-    }
+  for (int u = 0; u < W4Map<ROWS, COLS>::STEPS; ++u) {
+    int row, col;
+    W4Map<ROWS, COLS>::pos(tid, u, row, col);
+    v[u] = *reinterpret_cast<const float4*>(w + row * COLS + col);
+  }
+}
+template <int ROWS, int COLS, int STEPS>
+__device__ __forceinline__ void commit_w4(float* img, int ld, const float4 (&v)[STEPS], int tid) {
+  static_assert(STEPS == W4Map<ROWS, COLS>::STEPS, "register array does not match the weight shape");
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i4 = base + u * 256 + tid;
-      if (i4 < TOTAL4) {
-        const int idx = i4 * 4;
-        const int r = idx / COLS, c = idx % COLS;
-        float* p = img + r * ld + c;
-        p[0] = v[u].x; p[1] = v[u].y; p[2] = v[u].z; p[3] = v[u].w;
-      }
-    }
+  for (int u = 0; u < W4Map<ROWS, COLS>::STEPS; ++u) {
+    int row, col;
+    W4Map<ROWS, COLS>::pos(tid, u, row, col);
+    float* p = img + row * ld + col;
+    p[0] = v[u].x; p[1] = v[u].y; p[2] = v[u].z; p[3] = v[u].w;
   }
 }
 
@@ -125,7 +135,8 @@ struct CarArgs {
   const float* data;  // [rows][2]  (loc, v)
   const float* d2;    // [B][32]
   const float *wloc, *bloc, *w0, *b0, *w2, *b2, *w4, *b4;
-  float* dcar;        // [rows][32] gradient at the decoder output of the car's lane, one row per car
+  float* dpart;       // [tiles * 32][32] gradient at the decoder output, summed per traffic lane within a tile:
+                      // row tile*32 + s belongs to traffic lane (tile*32)/N + s
   float* slab;        // [gridDim.x][total]
   float* loss_part;   // [gridDim.x]
   Offsets off;
@@ -176,8 +187,13 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
     }
   };
   fetch_tile(blockIdx.x * 4 + wave);
-  load_weight_v4<128, 64, 8>(W0s, 65, g.w0, tid);
-  load_weight_v4<32, 128, 4>(W2s, 129, g.w2, tid);
+  {
+    float4 v0[8], v2[4];
+    request_w4<128, 64>(v0, g.w0, tid);
+    request_w4<32, 128>(v2, g.w2, tid);
+    commit_w4<128, 64>(W0s, 65, v0, tid);
+    commit_w4<32, 128>(W2s, 129, v2, tid);
+  }
   if (tid < 128) b0s[tid] = g.b0[tid];
   if (tid < 32) {
     b2s[tid] = g.b2[tid];
@@ -197,18 +213,15 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
   float* vs = locs + 32;
   float* dpre = vs + 32;
 
+  // weight-gradient accumulators; the first tile starts its products from a zero operand instead of
+  // zero-filling 192 registers that would then be live through its whole forward pass
   f32x16 dW0[4][2], dW2[4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    dW0[a][0] = splat(0.f);
-    dW0[a][1] = splat(0.f);
-    dW2[a] = splat(0.f);
-  }
   float db0[4] = {0.f, 0.f, 0.f, 0.f};
   float w4acc = 0.f, db2acc = 0.f, wlocacc = 0.f, blocacc = 0.f, b4acc = 0.f, lossacc = 0.f;
 
-  for (int tile = blockIdx.x * 4 + wave; tile < g.tiles; tile += gridDim.x * 4) {
-    if (tile != (int)blockIdx.x * 4 + wave) fetch_tile(tile);      // the first tile was requested in the prologue
+  auto process_tile = [&](auto first_tag, int tile) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    if (!FIRST) fetch_tile(tile);                                  // the first tile was requested in the prologue
     const float loc = in_loc, v = in_v;
     const bool valid = in_b >= 0;
     if (h == 0) {
@@ -307,7 +320,9 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
       store_tile<65>(half, 32, f1[2 * hh + 1], lane);
       wave_sync();
       {
-        f32x16 acc[2] = {dW2[2 * hh], dW2[2 * hh + 1]};
+        f32x16 acc[2];
+        acc[0] = FIRST ? splat(0.f) : dW2[2 * hh];
+        acc[1] = FIRST ? splat(0.f) : dW2[2 * hh + 1];
         wave_mma<2, 32, 1, 33, 65, 1>(acc, f2i, half, lane);
         dW2[2 * hh] = acc[0];
         dW2[2 * hh + 1] = acc[1];
@@ -333,7 +348,9 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
       wave_sync();
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
-        f32x16 acc[2] = {dW0[2 * hh + it][0], dW0[2 * hh + it][1]};
+        f32x16 acc[2];
+        acc[0] = FIRST ? splat(0.f) : dW0[2 * hh + it][0];
+        acc[1] = FIRST ? splat(0.f) : dW0[2 * hh + it][1];
         wave_mma<2, 32, 1, 65, 65, 1>(acc, half + 32 * it, cat, lane);
         dW0[2 * hh + it][0] = acc[0];
         dW0[2 * hh + it][1] = acc[1];
@@ -354,16 +371,46 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
       blocacc += sb;
       wlocacc += sw;
     }
-    // ---- gradient at the decoder output, one row per car (the per-lane backward sums each lane's rows)
+    // ---- gradient at the decoder output, summed per traffic lane within the tile on the matrix core:
+    //      P[s][col] = sum over the tile's cars of [lane of car == first lane of the tile + s] * dcat[car][col]
+    //      (exact: the indicator is 0 or 1, the cars of a lane add up in car order)
+    store_tile<33>(half, 0, dcat[0], lane);
+    wave_sync();
     {
-      const long row0 = (long)tile * 32;
+      const int b_first = __builtin_amdgcn_readfirstlane(in_b);
+      f32x16 P = splat(0.f);
+#pragma unroll
+      for (int k = 0; k < 32; k += 2) {
+        const int b0 = __builtin_amdgcn_readlane(in_b, k), b1 = __builtin_amdgcn_readlane(in_b, k + 1);
+        const int bk = h ? b1 : b0;
+        const float a = (bk >= 0 && bk - b_first == r) ? 1.f : 0.f;
+        P = __builtin_amdgcn_mfma_f32_32x32x2f32(a, half[(k + h) * 33 + r], P, 0, 0, 0);
+      }
+      const long left = g.rows - (long)tile * 32;
+      const int b_last = __shfl(in_b, left < 32 ? (int)left - 1 : 31, 64);
+      const int nslots = b_last - b_first + 1;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const long row = row0 + drow(i, h);
-        if (row < g.rows) g.dcar[row * 32 + r] = dcat[0][i];
+        const int slot = drow(i, h);
+        if (slot < nslots) g.dpart[((long)tile * 32 + slot) * 32 + r] = P[i];
       }
     }
+    wave_sync();
     HHRL_STAMP(0, 9);
+  };
+  {
+    const int tile0 = blockIdx.x * 4 + wave, stride = gridDim.x * 4;
+    if (tile0 < g.tiles) {
+      process_tile(std::true_type(), tile0);
+      for (int tile = tile0 + stride; tile < g.tiles; tile += stride) process_tile(std::false_type(), tile);
+    } else {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        dW0[a][0] = splat(0.f);
+        dW0[a][1] = splat(0.f);
+        dW2[a] = splat(0.f);
+      }
+    }
   }
 
   // ---- combine the two lane halves (they hold different rows of the same columns)
@@ -463,7 +510,7 @@ struct LaneArgs {
   const float* b[NLAYER];
   float* d2;           // [B][32] forward output
   float* act;          // [tiles][LN_ACT_FLOATS] activation images: written by the forward, read by the backward kernel
-  const float* dcar;   // [B*N][32] backward input: gradient at d2, one row per car
+  const float* dpart;  // [car tiles * 32][32] backward input: gradient at d2, one row per (car tile, traffic lane in it)
   float* slab;
   float* kl_part;      // [gridDim.x]
   Offsets off;
@@ -542,11 +589,13 @@ __device__ __forceinline__ void store_block16(float* img, int row0, int col0, co
   for (int e = 0; e < 4; ++e) img[(row0 + 4 * q + e) * LD + col0 + j] = c[e];
 }
 
-// ---- registers that carry a tile's global loads from request to LDS
-struct LaneRegs {
-  float4 rho2[8], rho0[4], dec2[4], phi2;
-  float head[8], dec0[8], bias[2], cars[4];
-};
+// ---- registers that carry global loads from request to LDS, grouped by when the chain needs them:
+//      group P (phi.2, rho.0, car states), group R (rho.2, heads), group D (decoder.0, decoder.2), biases.
+//      Every request of a tile is issued before the first LDS write, so the round trips overlap.
+struct RegsP { float4 rho0[4], phi2; float cars[4]; };
+struct RegsR { float4 rho2[8]; float head[8]; };
+struct RegsD { float4 dec2[4]; float dec0[8]; };
+struct RegsB { float bias[2]; };
 
 __device__ __forceinline__ const float* lane_bias_src(const LaneArgs& g, int idx) {
   const int gd = g.g;
@@ -562,42 +611,6 @@ __device__ __forceinline__ const float* lane_bias_src(const LaneArgs& g, int idx
   return nullptr;
 }
 
-__device__ __forceinline__ void lane_request_weights(LaneRegs& R, const LaneArgs& g, int tid) {
-  const float4* p = reinterpret_cast<const float4*>(g.w[RHO2]);
-#pragma unroll
-  for (int u = 0; u < 8; ++u) R.rho2[u] = p[u * 256 + tid];
-  p = reinterpret_cast<const float4*>(g.w[RHO0]);
-#pragma unroll
-  for (int u = 0; u < 4; ++u) R.rho0[u] = p[u * 256 + tid];
-  p = reinterpret_cast<const float4*>(g.w[DEC2]);
-#pragma unroll
-  for (int u = 0; u < 4; ++u) R.dec2[u] = p[u * 256 + tid];
-  R.phi2 = tid < 128 ? reinterpret_cast<const float4*>(g.w[PHI2])[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
-  const int gd = g.g, nh = 128 * gd, nd = 128 * gd;     // heads: 2g rows x 64; decoder.0: 128 rows x g
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int e = u * 256 + tid;
-    R.head[u] = e < nh ? (e < 64 * gd ? g.w[MEAN][e] : g.w[LOGVAR][e - 64 * gd]) : 0.f;
-    R.dec0[u] = e < nd ? g.w[DEC0][e] : 0.f;
-  }
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const float* src = lane_bias_src(g, u * 256 + tid);
-    R.bias[u] = src ? *src : 0.f;
-  }
-}
-
-__device__ __forceinline__ void lane_request_cars(LaneRegs& R, const LaneArgs& g, int row0, int tid) {
-  const long base = (long)row0 * g.N * 2;
-  const long lim = (long)g.B * g.N * 2;
-  const int n = g.N <= STAGE_MAX_CARS ? 64 * g.N : 0;
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int i = u * 256 + tid;
-    R.cars[u] = (i < n && base + i < lim) ? g.data[base + i] : 0.f;
-  }
-}
-
 template <int COLS>
 __device__ __forceinline__ void commit4(float* img, int ld, int i4, const float4& v) {
   const int idx = i4 * 4, r = idx / COLS, c = idx % COLS;
@@ -605,30 +618,14 @@ __device__ __forceinline__ void commit4(float* img, int ld, int i4, const float4
   p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
 }
 
-// Zero padding of the images first (disjoint from what lane_commit_weights writes, so no barrier in between).
-__device__ __forceinline__ void lane_zero_pads(float* lds, const LaneArgs& g, int tid) {
-  const int gd = g.g;
-  for (int i = tid; i < 32 * 65; i += 256)
-    if (i / 65 >= 2 * gd) lds[LW_HEAD + i] = 0.f;
-  for (int i = tid; i < 128 * 17; i += 256)
-    if (i % 17 >= gd) lds[LW_DEC0 + i] = 0.f;
-}
-
-__device__ __forceinline__ void lane_commit_weights(float* lds, const LaneRegs& R, const LaneArgs& g, int tid) {
+__device__ __forceinline__ void request_bias(RegsB& R, const LaneArgs& g, int tid) {
 #pragma unroll
-  for (int u = 0; u < 8; ++u) commit4<128>(lds + LW_RHO2, 129, u * 256 + tid, R.rho2[u]);
-#pragma unroll
-  for (int u = 0; u < 4; ++u) commit4<32>(lds + LW_RHO0, 33, u * 256 + tid, R.rho0[u]);
-#pragma unroll
-  for (int u = 0; u < 4; ++u) commit4<128>(lds + LW_DEC2, 129, u * 256 + tid, R.dec2[u]);
-  if (tid < 128) commit4<16>(lds + LW_PHI2, 17, tid, R.phi2);
-  const int gd = g.g, nh = 128 * gd, nd = 128 * gd, lg = __ffs(gd) - 1;
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int e = u * 256 + tid;
-    if (e < nh) lds[LW_HEAD + (e >> 6) * 65 + (e & 63)] = R.head[u];
-    if (e < nd) lds[LW_DEC0 + (e >> lg) * 17 + (e & (gd - 1))] = R.dec0[u];
+  for (int u = 0; u < 2; ++u) {
+    const float* src = lane_bias_src(g, u * 256 + tid);
+    R.bias[u] = src ? *src : 0.f;
   }
+}
+__device__ __forceinline__ void commit_bias(float* lds, const RegsB& R, int tid) {
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int idx = u * 256 + tid;
@@ -636,14 +633,101 @@ __device__ __forceinline__ void lane_commit_weights(float* lds, const LaneRegs& 
   }
 }
 
-__device__ __forceinline__ void lane_commit_cars(float* lds, const LaneRegs& R, const LaneArgs& g, int tid) {
+__device__ __forceinline__ void request_cars(float (&cars)[4], const LaneArgs& g, int row0, int tid) {
+  const long base = (long)row0 * g.N * 2;
+  const long lim = (long)g.B * g.N * 2;
   const int n = g.N <= STAGE_MAX_CARS ? 64 * g.N : 0;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int i = u * 256 + tid;
-    if (i < n) lds[LI_CARS + i] = R.cars[u];
+    cars[u] = (i < n && base + i < lim) ? g.data[base + i] : 0.f;
   }
 }
+__device__ __forceinline__ void commit_cars(float* lds, const float (&cars)[4], const LaneArgs& g, int tid) {
+  const int n = g.N <= STAGE_MAX_CARS ? 64 * g.N : 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = u * 256 + tid;
+    if (i < n) lds[LI_CARS + i] = cars[u];
+  }
+}
+
+__device__ __forceinline__ void request_P(RegsP& R, const LaneArgs& g, int row0, int tid) {
+  request_w4<128, 32>(R.rho0, g.w[RHO0], tid);
+  R.phi2 = tid < 128 ? reinterpret_cast<const float4*>(g.w[PHI2])[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+  request_cars(R.cars, g, row0, tid);
+}
+__device__ __forceinline__ void commit_P(float* lds, const RegsP& R, const LaneArgs& g, int tid) {
+  commit_w4<128, 32>(lds + LW_RHO0, 33, R.rho0, tid);
+  if (tid < 128) commit4<16>(lds + LW_PHI2, 17, tid, R.phi2);
+  commit_cars(lds, R.cars, g, tid);
+}
+
+__device__ __forceinline__ void request_R(RegsR& R, const LaneArgs& g, int tid) {
+  request_w4<64, 128>(R.rho2, g.w[RHO2], tid);
+  const int gd = g.g, nh = 128 * gd;                   // heads: 2g rows x 64
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int e = u * 256 + tid;
+    R.head[u] = e < nh ? (e < 64 * gd ? g.w[MEAN][e] : g.w[LOGVAR][e - 64 * gd]) : 0.f;
+  }
+}
+__device__ __forceinline__ void commit_R(float* lds, const RegsR& R, const LaneArgs& g, int tid) {
+  commit_w4<64, 128>(lds + LW_RHO2, 129, R.rho2, tid);
+  const int gd = g.g, nh = 128 * gd;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int e = u * 256 + tid;
+    if (e < nh) lds[LW_HEAD + (e >> 6) * 65 + (e & 63)] = R.head[u];
+  }
+  for (int i = tid; i < 32 * 65; i += 256)             // rows >= 2g of the heads image are zero
+    if (i / 65 >= 2 * gd) lds[LW_HEAD + i] = 0.f;
+}
+
+__device__ __forceinline__ void request_D(RegsD& R, const LaneArgs& g, int tid) {
+  request_w4<32, 128>(R.dec2, g.w[DEC2], tid);
+  const int nd = 128 * g.g;                            // decoder.0: 128 rows x g
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int e = u * 256 + tid;
+    R.dec0[u] = e < nd ? g.w[DEC0][e] : 0.f;
+  }
+}
+__device__ __forceinline__ void commit_D(float* lds, const RegsD& R, const LaneArgs& g, int tid) {
+  commit_w4<32, 128>(lds + LW_DEC2, 129, R.dec2, tid);
+  const int gd = g.g, nd = 128 * gd, lg = __ffs(gd) - 1;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int e = u * 256 + tid;
+    if (e < nd) lds[LW_DEC0 + (e >> lg) * 17 + (e & (gd - 1))] = R.dec0[u];
+  }
+  for (int i = tid; i < 128 * 17; i += 256)            // columns >= g of the decoder.0 image are zero
+    if (i % 17 >= gd) lds[LW_DEC0 + i] = 0.f;
+}
+
+// A contiguous range of the saved activation images, 16 bytes per thread and step.
+template <int LO, int HI>
+struct ActRange {
+  static_assert(LO % 4 == 0 && HI % 4 == 0, "image boundaries are multiples of 4 floats");
+  static constexpr int V4 = (HI - LO) / 4, STEPS = (V4 + 255) / 256;
+  float4 v[STEPS];
+  __device__ __forceinline__ void request(const float* act_tile, int tid) {
+    const float4* src = reinterpret_cast<const float4*>(act_tile + (LO - LI_H1));
+#pragma unroll
+    for (int u = 0; u < STEPS; ++u) {
+      const int i4 = u * 256 + tid;
+      v[u] = i4 < V4 ? src[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __device__ __forceinline__ void commit(float* lds, int tid) const {
+    float4* dst = reinterpret_cast<float4*>(lds + LO);
+#pragma unroll
+    for (int u = 0; u < STEPS; ++u) {
+      const int i4 = u * 256 + tid;
+      if (i4 < V4) dst[i4] = v[u];
+    }
+  }
+};
 
 // ------------------------------------------------------------------ forward
 __global__ __launch_bounds__(256, 1) void vae_lane_forward_kernel(LaneArgs g) {
@@ -663,22 +747,26 @@ __global__ __launch_bounds__(256, 1) void vae_lane_forward_kernel(LaneArgs g) {
   float* Id2 = lds + LI_D2;
   const bool staged = g.N <= STAGE_MAX_CARS;
   HHRL_STAMP(1, 0);
-  {
-    LaneRegs R;
-    lane_request_weights(R, g, tid);
-    lane_request_cars(R, g, blockIdx.x * 32, tid);
-    lane_zero_pads(lds, g, tid);
-    lane_commit_weights(lds, R, g, tid);
-    lane_commit_cars(lds, R, g, tid);
-  }
+  RegsB rB;
+  RegsP rP;
+  RegsR rR;
+  RegsD rD;
+  request_bias(rB, g, tid);
+  request_P(rP, g, blockIdx.x * 32, tid);
+  request_R(rR, g, tid);
+  request_D(rD, g, tid);
+  commit_bias(lds, rB, tid);
+  commit_P(lds, rP, g, tid);
+  commit_R(lds, rR, g, tid);
+  commit_D(lds, rD, g, tid);
   __syncthreads();
   HHRL_STAMP(1, 1);
   for (int tile = blockIdx.x; tile < g.tiles; tile += gridDim.x) {
     const int row0 = tile * 32;
-    if (tile != (int)blockIdx.x) {               // later tiles: the images of the previous tile are dead (barrier at loop end)
-      LaneRegs R;
-      lane_request_cars(R, g, row0, tid);
-      lane_commit_cars(lds, R, g, tid);
+    const bool first = tile == (int)blockIdx.x;
+    if (!first) {                                // later tiles: the images of the previous tile are dead (barrier at loop end)
+      request_cars(rP.cars, g, row0, tid);
+      commit_cars(lds, rP.cars, g, tid);
       __syncthreads();
     }
     HHRL_STAMP(1, 2);
@@ -779,6 +867,9 @@ __global__ __launch_bounds__(256, 1) void vae_lane_forward_kernel(LaneArgs g) {
 }
 
 // ------------------------------------------------------------------ backward
+// SINGLE: the grid covers every tile (one tile per workgroup, the case up to 8192 traffic lanes); a layer's
+// slab entries are then written right after the phase that completes them, under the later phases.
+template <bool SINGLE>
 __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -801,65 +892,111 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
   // weight-gradient tiles owned by this wave, kept across tiles
   f32x16 aDec2 = splat(0.f), aDec0 = splat(0.f), aHead = splat(0.f), aRho2a = splat(0.f), aRho2b = splat(0.f);
   f32x16 aRho0 = splat(0.f), aPhi2 = splat(0.f);
-  // bias gradients: thread tid owns column tid of each layer
+  // bias gradients: one thread owns a column of a layer
   float bDec2 = 0.f, bDec0 = 0.f, bHead = 0.f, bRho2 = 0.f, bRho0 = 0.f, bPhi2 = 0.f;
   float gPhi0a = 0.f, gPhi0b = 0.f, gPhi0c = 0.f;     // threads 0..47: dW_phi0[k][0], dW_phi0[k][1], db_phi0[k]
   float klacc = 0.f;
 
-  for (int tile = blockIdx.x; tile < g.tiles; tile += gridDim.x) {
-    const int row0 = tile * 32;
-    // ---- request everything the tile needs, then write it to LDS
-    {
-      LaneRegs R;
-      const bool first = tile == (int)blockIdx.x;
-      if (first) lane_request_weights(R, g, tid);
-      lane_request_cars(R, g, row0, tid);
-      float4 av[ACT_PER_THREAD];
-      {
-        const float4* src = reinterpret_cast<const float4*>(g.act + (long)tile * LN_ACT_FLOATS);
+  float* slab = g.slab + (long)blockIdx.x * g.off.total;
+  auto put_tile = [&](long base, int ld, int row_lim, int col0, int col_lim, const f32x16& t) {
+    const int col = col0 + r;
 #pragma unroll
-        for (int u = 0; u < ACT_PER_THREAD; ++u) {
-          const int i4 = u * 256 + tid;
-          av[u] = i4 < ACT_V4 ? src[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-      }
-      // dd2 of a lane = sum over its cars, in car order
-      float dd2v[4];
+    for (int i = 0; i < 16; ++i) {
+      const int row = drow(i, h);
+      if (row < row_lim && col < col_lim) slab[base + (long)row * ld + col] = t[i];
+    }
+  };
+
+  auto write_dec2 = [&]() {
+    put_tile(g.off.w[DEC2], 128, 32, 32 * wave, 128, aDec2);
+    if (tid < 32) slab[g.off.b[DEC2] + tid] = bDec2;
+  };
+  auto write_dec0 = [&]() {
+    put_tile(g.off.w[DEC0] + (long)32 * wave * gd, gd, 32, 0, gd, aDec0);
+    if (tid >= 128) slab[g.off.b[DEC0] + tid - 128] = bDec0;
+  };
+  auto write_heads = [&]() {
+    if (wave < 2) {
+      const int col = 32 * wave + r;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int idx = u * 256 + tid, rr = idx >> 5, c = idx & 31;
-        float sum = 0.f;
-        if (row0 + rr < g.B) {
-          const float* src = g.dcar + (long)(row0 + rr) * g.N * 32 + c;
-          int n = 0;
-          for (; n + 4 <= g.N; n += 4) {
-            const float a0 = src[(long)n * 32], a1 = src[(long)(n + 1) * 32], a2 = src[(long)(n + 2) * 32],
-                        a3 = src[(long)(n + 3) * 32];
-            sum = (((sum + a0) + a1) + a2) + a3;
-          }
-          for (; n < g.N; ++n) sum += src[(long)n * 32];
-        }
-        dd2v[u] = sum;
-      }
-      if (first) {
-        lane_zero_pads(lds, g, tid);
-        lane_commit_weights(lds, R, g, tid);
-      }
-      lane_commit_cars(lds, R, g, tid);
-      {
-        float4* dst = reinterpret_cast<float4*>(lds + LI_H1);
-#pragma unroll
-        for (int u = 0; u < ACT_PER_THREAD; ++u) {
-          const int i4 = u * 256 + tid;
-          if (i4 < ACT_V4) dst[i4] = av[u];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int idx = u * 256 + tid;
-        Id2[(idx >> 5) * 33 + (idx & 31)] = dd2v[u];
+      for (int i = 0; i < 16; ++i) {
+        const int row = drow(i, h);
+        if (row < gd) slab[g.off.w[MEAN] + (long)row * 64 + col] = aHead[i];
+        else if (row < 2 * gd) slab[g.off.w[LOGVAR] + (long)(row - gd) * 64 + col] = aHead[i];
       }
     }
+    if (tid < gd) slab[g.off.b[MEAN] + tid] = bHead;
+    else if (tid < 2 * gd) slab[g.off.b[LOGVAR] + tid - gd] = bHead;
+  };
+  auto write_rho2 = [&]() {
+    const int it = wave >> 1, jt0 = (wave & 1) * 2;
+    put_tile(g.off.w[RHO2] + (long)32 * it * 128, 128, 32, 32 * jt0, 128, aRho2a);
+    put_tile(g.off.w[RHO2] + (long)32 * it * 128, 128, 32, 32 * (jt0 + 1), 128, aRho2b);
+    if (tid < 64) slab[g.off.b[RHO2] + tid] = bRho2;
+  };
+  auto write_rho0 = [&]() {
+    put_tile(g.off.w[RHO0] + (long)32 * wave * 32, 32, 32, 0, 32, aRho0);
+    if (tid < 128) slab[g.off.b[RHO0] + tid] = bRho0;
+  };
+  auto write_phi2 = [&]() {
+    if (wave == 0) put_tile(g.off.w[PHI2], 16, 32, 0, 16, aPhi2);
+    if (wave == 1 && lane < 32) slab[g.off.b[PHI2] + lane] = bPhi2;
+  };
+
+  int tile = blockIdx.x;
+  do {
+    const int row0 = tile * 32;
+    const bool first = SINGLE || tile == (int)blockIdx.x;
+    // ---- request everything the tile needs in the order of use
+    RegsB rB;
+    RegsD rD;
+    RegsR rR;
+    RegsP rP;
+    ActRange<LI_ML, LI_D2> actD;      // mean|logvar, z, d1
+    ActRange<LI_R1, LI_ML> actR;      // r1, r2
+    ActRange<LI_H1, LI_R1> actP;      // h1, pooled
+    const float* act_tile = g.act + (long)tile * LN_ACT_FLOATS;
+    actD.request(act_tile, tid);
+    if (first) {
+      request_bias(rB, g, tid);
+      request_D(rD, g, tid);
+    }
+    // dd2 of a traffic lane = sum of the per-(lane, car tile) partial rows of the car tiles its cars span
+    float dd2v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = u * 256 + tid, rr = idx >> 5, c = idx & 31;
+      const int b = row0 + rr;
+      float sum = 0.f;
+      if (b < g.B) {
+        const unsigned n = (unsigned)g.N, lo = (unsigned)b * n;
+        const unsigned t0 = lo >> 5, t1 = (lo + n - 1) >> 5;
+        for (unsigned t = t0; t <= t1; ++t) {
+          const unsigned slot = (unsigned)b - (t * 32u) / n;
+          sum += g.dpart[((long)t * 32 + slot) * 32 + c];
+        }
+      }
+      dd2v[u] = sum;
+    }
+    actR.request(act_tile, tid);
+    if (first) request_R(rR, g, tid);
+    actP.request(act_tile, tid);
+    if (first) request_P(rP, g, row0, tid); else request_cars(rP.cars, g, row0, tid);
+    // ---- and write it to LDS
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = u * 256 + tid;
+      Id2[(idx >> 5) * 33 + (idx & 31)] = dd2v[u];
+    }
+    actD.commit(lds, tid);
+    if (first) {
+      commit_bias(lds, rB, tid);
+      commit_D(lds, rD, g, tid);
+    }
+    actR.commit(lds, tid);
+    if (first) commit_R(lds, rR, g, tid);
+    actP.commit(lds, tid);
+    if (first) commit_P(lds, rP, g, tid); else commit_cars(lds, rP.cars, g, tid);
     __syncthreads();
     HHRL_STAMP(2, 1);
     // ---- decoder.2 backward: dW[32][128] += dd2^T d1, db, dd1 = (dd2 W) o relu'(d1) in place (column block `wave`)
@@ -878,6 +1015,7 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
         *p = *p > 0.f ? d[0][i] : 0.f;
       }
     }
+    if (SINGLE) write_dec2();
     __syncthreads();
     HHRL_STAMP(2, 2);
     // ---- decoder.0 backward: dW[128][g] += dd1^T z (row tile `wave`), db, dz = dd1 W (waves 0 and 1, 16 rows each)
@@ -886,13 +1024,13 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
       wave_mma<1, 32, 1, 129, 17, 1>(acc, Id1 + 32 * wave, Iz, lane);
       aDec0 = acc[0];
       if (wave >= 2) {
-        const int c = tid - 128;
-        bDec0 += colsum32(Id1, 129, c);
+        bDec0 += colsum32(Id1, 129, tid - 128);
       } else {
         const f32x4 c = wave_mma16<128, 129, 1, 17, 1>(Id1 + 16 * wave * 129, lds + LW_DEC0, lane, 0.f);
         store_block16<33>(Itmp, 16 * wave, 0, c, lane);
       }
     }
+    if (SINGLE) write_dec0();
     __syncthreads();
     HHRL_STAMP(2, 3);
     // ---- latent gradient (KL + reparameterisation): dml = [dz + mean | dz*eps*0.5*std + 0.5*(exp(lv)-1) | 0...]
@@ -929,6 +1067,7 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
       __syncthreads();
       if (wave >= 2) store_tile<65>(Ir2, 32 * (wave - 2), d[0], lane);
     }
+    if (SINGLE) write_heads();
     __syncthreads();
     HHRL_STAMP(2, 5);
     // ---- rho.2 backward: dW[64][128] += dr2^T r1 (two tiles per wave), db, dr1 = (dr2 W) o relu'(r1) in place
@@ -949,6 +1088,7 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
         *p = *p > 0.f ? d[0][i] : 0.f;
       }
     }
+    if (SINGLE) write_rho2();
     __syncthreads();
     HHRL_STAMP(2, 6);
     // ---- rho.0 backward: dW[128][32] += dr1^T pooled (row tile `wave`), db, dpooled = dr1 W (16x16 blocks) -> ml slot
@@ -960,13 +1100,14 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
       const f32x4 c = wave_mma16<128, 129, 1, 33, 1>(Ir1 + 16 * rb * 129, lds + LW_RHO0 + 16 * cb, lane, 0.f);
       store_block16<33>(Iml, 16 * rb, 16 * cb, c, lane);
     }
+    if (SINGLE) write_rho0();
     __syncthreads();
     HHRL_STAMP(2, 7);
     // ---- phi.2 backward on the summed hidden: dW[32][16] += dpooled^T h1s (wave 0), db = N colsum(dpooled) (wave 1),
     //      t = dpooled W_phi2 (waves 2 and 3): gradient at the hidden layer of every car of the lane, before its ReLU mask
     if (wave == 0) {
       f32x16 acc[1] = {aPhi2};
-      wave_mma<1, 32, 1, 33, 33, 1>(acc, Iml, Ih1, lane);       // columns >= 16 are junk, dropped at the end
+      wave_mma<1, 32, 1, 33, 33, 1>(acc, Iml, Ih1, lane);       // columns >= 16 are junk, dropped below
       aPhi2 = acc[0];
     } else if (wave == 1) {
       if (lane < 32) bPhi2 += (float)g.N * colsum32(Iml, 33, lane);
@@ -974,6 +1115,7 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
       const f32x4 c = wave_mma16<32, 33, 1, 17, 1>(Iml + 16 * (wave - 2) * 33, lds + LW_PHI2, lane, 0.f);
       store_block16<33>(Itmp, 16 * (wave - 2), 0, c, lane);
     }
+    if (SINGLE) write_phi2();
     __syncthreads();
     HHRL_STAMP(2, 8);
     // ---- phi.0 backward: per (lane, hidden unit) walk the cars again and apply the ReLU mask
@@ -1005,46 +1147,16 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
     }
     __syncthreads();
     HHRL_STAMP(2, 9);
-  }
+  } while (!SINGLE && (tile += gridDim.x) < g.tiles);
 
-  // ---- write this workgroup's slab
-  float* slab = g.slab + (long)blockIdx.x * g.off.total;
-  auto put_tile = [&](long base, int ld, int row_lim, int col0, int col_lim, const f32x16& t) {
-    const int col = col0 + r;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = drow(i, h);
-      if (row < row_lim && col < col_lim) slab[base + (long)row * ld + col] = t[i];
-    }
-  };
-  put_tile(g.off.w[DEC2], 128, 32, 32 * wave, 128, aDec2);
-  put_tile(g.off.w[DEC0] + (long)32 * wave * gd, gd, 32, 0, gd, aDec0);
-  if (wave < 2) {
-    const int col = 32 * wave + r;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = drow(i, h);
-      if (row < gd) slab[g.off.w[MEAN] + (long)row * 64 + col] = aHead[i];
-      else if (row < 2 * gd) slab[g.off.w[LOGVAR] + (long)(row - gd) * 64 + col] = aHead[i];
-    }
+  if (!SINGLE) {
+    write_dec2();
+    write_dec0();
+    write_heads();
+    write_rho2();
+    write_rho0();
+    write_phi2();
   }
-  {
-    const int it = wave >> 1, jt0 = (wave & 1) * 2;
-    put_tile(g.off.w[RHO2] + (long)32 * it * 128, 128, 32, 32 * jt0, 128, aRho2a);
-    put_tile(g.off.w[RHO2] + (long)32 * it * 128, 128, 32, 32 * (jt0 + 1), 128, aRho2b);
-  }
-  put_tile(g.off.w[RHO0] + (long)32 * wave * 32, 32, 32, 0, 32, aRho0);
-  if (wave == 0) put_tile(g.off.w[PHI2], 16, 32, 0, 16, aPhi2);
-  // bias gradients: the thread that accumulated a column writes it
-  if (tid < 32) {
-    slab[g.off.b[DEC2] + tid] = bDec2;
-    if (tid < gd) slab[g.off.b[MEAN] + tid] = bHead;
-    else if (tid < 2 * gd) slab[g.off.b[LOGVAR] + tid - gd] = bHead;
-  }
-  if (wave == 1 && lane < 32) slab[g.off.b[PHI2] + lane] = bPhi2;
-  if (tid >= 128) slab[g.off.b[DEC0] + tid - 128] = bDec0;
-  if (tid < 128) slab[g.off.b[RHO0] + tid] = bRho0;
-  if (tid < 64) slab[g.off.b[RHO2] + tid] = bRho2;
   if (tid < 16) {
     slab[g.off.w[PHI0] + 2 * tid] = gPhi0a;
   } else if (tid < 32) {
@@ -1110,7 +1222,7 @@ __global__ __launch_bounds__(256) void vae_reduce_grads_kernel(const float* __re
 }
 
 struct Ws {
-  float *d2, *dcar, *act, *loss_part, *kl_part, *slab;
+  float *d2, *dpart, *act, *loss_part, *kl_part, *slab;
   long total;
 };
 
@@ -1133,7 +1245,7 @@ static Ws carve(float* ws, int B, int N, int g, long n_flat) {
   long off = 0;
   auto take = [&](long n) { float* p = ws ? ws + off : nullptr; off += a64(n); return p; };
   w.d2 = take((long)B * 32);
-  w.dcar = take((long)B * N * 32);
+  w.dpart = take(((long)B * N + 31) / 32 * 32 * 32);
   w.act = take((long)((B + 31) / 32) * LN_ACT_FLOATS);
   w.loss_part = take(256);
   w.kl_part = take(256);
@@ -1194,9 +1306,11 @@ static int vae_step_impl(float* params, float* grads, float* m, float* v, const 
                                         hipFuncAttributeMaxDynamicSharedMemorySize, CAR_LDS_FLOATS * 4);
     hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(vae_lane_forward_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS_FLOATS * 4);
-    hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(vae_lane_backward_kernel),
+    hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(vae_lane_backward_kernel<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS_FLOATS * 4);
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess)
+    hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(vae_lane_backward_kernel<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS_FLOATS * 4);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess)
       return fail(HHRL_ERR_HIP, "vae_train_step: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     attr_done = true;
   }
@@ -1209,7 +1323,7 @@ static int vae_step_impl(float* params, float* grads, float* m, float* v, const 
     la.b[l] = params + off.b[l];
   }
   la.d2 = w.d2;
-  la.dcar = w.dcar;
+  la.dpart = w.dpart;
   la.act = w.act;
   la.slab = w.slab;
   la.kl_part = w.kl_part;
@@ -1230,7 +1344,7 @@ static int vae_step_impl(float* params, float* grads, float* m, float* v, const 
   ca.w0 = la.w[FUNC0]; ca.b0 = la.b[FUNC0];
   ca.w2 = la.w[FUNC2]; ca.b2 = la.b[FUNC2];
   ca.w4 = la.w[FUNC4]; ca.b4 = la.b[FUNC4];
-  ca.dcar = w.dcar;
+  ca.dpart = w.dpart;
   ca.slab = w.slab;
   ca.loss_part = w.loss_part;
   ca.off = off;
@@ -1246,7 +1360,10 @@ static int vae_step_impl(float* params, float* grads, float* m, float* v, const 
   }
   {
     ProfScope ps("vae_lane_backward_kernel", st, 4.0 * lane_macs * B, 4.0 * B * (2.0 * N + g + 32));
-    hipLaunchKernelGGL(vae_lane_backward_kernel, dim3(nlane), dim3(256), LN_LDS_FLOATS * 4, st, la);
+    if (nlane >= la.tiles)
+      hipLaunchKernelGGL(vae_lane_backward_kernel<true>, dim3(nlane), dim3(256), LN_LDS_FLOATS * 4, st, la);
+    else
+      hipLaunchKernelGGL(vae_lane_backward_kernel<false>, dim3(nlane), dim3(256), LN_LDS_FLOATS * 4, st, la);
     HHRL_TRY(launch_status("vae_lane_backward_kernel"));
   }
   {

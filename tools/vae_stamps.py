@@ -22,7 +22,7 @@ from hhrl_vae_amd import _lib
 from hhrl_vae_amd.algorithm import Encoder
 
 CAR = ["start", "weights in LDS", "cat image", "func.0 fwd", "func.2 fwd", "func.4+err", "func.4 bwd",
-       "bwd half 0", "bwd half 1", "dcar rows stored", "pre-combine barrier", "combine", "slab written"]
+       "bwd half 0", "bwd half 1", "per-lane partial rows", "pre-combine barrier", "combine", "slab written"]
 CHAIN = ["start", "weights in LDS", "cars staged", "phi.0", "phi.2", "rho.0", "rho.2", "heads", "reparam", "dec.0", "dec.2"]
 LFWD = CHAIN + ["d2 + activations stored"]
 LBWD = ["start", "weights, activations, dd2 in LDS", "dec.2 bwd", "dec.0 bwd", "latent", "heads bwd", "rho.2 bwd",
