@@ -19,12 +19,35 @@ _L = C.c_long
 _F = C.c_float
 _D = C.c_double
 
+class LstmDesc(C.Structure):
+    """hhrl_lstm_desc of include/hhrl_hip.h."""
+    _fields_ = [("obs", _P), ("ldobs", _I), ("o", _I), ("params", _P), ("grads", _P), ("out", _P), ("ldo", _I),
+                ("d_out", _P), ("lddo", _I), ("ws", _P)]
+
+
+LSTM_GROUP_MAX = 16
+
+
+class LinearFwdDesc(C.Structure):
+    """hhrl_linear_fwd_desc of include/hhrl_hip.h."""
+    _fields_ = [("x", _P), ("ldx", _I), ("w", _P), ("b", _P), ("y", _P), ("ldy", _I),
+                ("K", _I), ("N", _I), ("act", _I), ("accumulate", _I)]
+
+
+class LinearBwdDesc(C.Structure):
+    """hhrl_linear_bwd_desc of include/hhrl_hip.h."""
+    _fields_ = [("x", _P), ("ldx", _I), ("w", _P), ("y", _P), ("ldy", _I), ("dy", _P), ("lddy", _I),
+                ("dx", _P), ("lddx", _I), ("dx_accumulate", _I), ("dw", _P), ("db", _P),
+                ("K", _I), ("N", _I), ("act", _I)]
+
 # name -> (restype, argtypes); mirrors include/hhrl_hip.h one to one
 SIGNATURES = {
     "hhrl_version": (_I, []),
     "hhrl_last_error": (C.c_char_p, []),
     "hhrl_linear_forward": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "hhrl_linear_backward": (_I, [_P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "hhrl_linear_forward_group": (_I, [_P, _I, _I, _P]),
+    "hhrl_linear_backward_group": (_I, [_P, _I, _I, _P]),
     "hhrl_sum_pool": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     "hhrl_broadcast_rows": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     "hhrl_copy2d": (_I, [_P, _I, _P, _I, _I, _I, _P]),
@@ -41,6 +64,8 @@ SIGNATURES = {
     "hhrl_lstm_workspace_floats": (_L, [_I, _I, _I, _I]),
     "hhrl_lstm_forward": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "hhrl_lstm_backward": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "hhrl_lstm_forward_group": (_I, [_P, _I, _I, _I, _I, _P]),
+    "hhrl_lstm_backward_group": (_I, [_P, _I, _I, _I, _I, _P]),
     "hhrl_adam_step": (_I, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _I, _D, _P]),
     "hhrl_adam_stage": (_I, [_P, _D, _D, _D, _D, _I, _D, _P]),
     "hhrl_adam_step_dev": (_I, [_P, _P, _P, _P, _L, _P, _P]),

@@ -94,4 +94,28 @@ struct ProfScope {
 int gemm(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj, float* C, long ldc,
          int M, int N, int K, const float* bias, int act, int mode, hipStream_t st);
 
+// The same product as a value, and several independent ones enqueued as ONE launch when all of them
+// are small (batch-64 agent updates are bound by the number of launches, not by their work).
+struct GemmArgs {
+  const float* A;
+  long a_si, a_sk;
+  const float* B;
+  long b_sk, b_sj;
+  float* C;
+  long ldc;
+  const float* bias;
+  int M, N, K;
+  int k_chunk;
+  int act, mode;
+  int a_kcontig, b_kcontig;
+};
+constexpr int kGemmGroupMax = 16;
+struct GemmGroup {
+  GemmArgs g[kGemmGroupMax];
+  int splits;
+};
+GemmArgs gemm_args(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj, float* C, long ldc,
+                   int M, int N, int K, const float* bias, int act, int mode);
+int gemm_group(const GemmArgs* gs, int n, hipStream_t st);
+
 }  // namespace hhrl

@@ -18,20 +18,6 @@ namespace hhrl {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-struct GemmArgs {
-  const float* A;
-  long a_si, a_sk;
-  const float* B;
-  long b_sk, b_sj;
-  float* C;
-  long ldc;
-  const float* bias;
-  int M, N, K;
-  int k_chunk;
-  int act, mode;
-  int a_kcontig, b_kcontig;
-};
-
 constexpr int BK = 16;
 
 template <int TM, int TN>
@@ -126,13 +112,13 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
 // in wave order.  Many small workgroups instead of a few long-running ones.
 constexpr int SKC = 64;   // reduction elements staged per wave per chunk
 
-__global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_small_body(const GemmArgs& g, int bx, int by, int bz) {
   __shared__ float stage[4][2][SKC][33];
   __shared__ float part[4][32][33];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
-  const int zbeg = blockIdx.z * g.k_chunk;
+  const int i0 = by * 32, j0 = bx * 32;
+  const int zbeg = bz * g.k_chunk;
   const int zend = min(g.K, zbeg + g.k_chunk);
   // this wave's share of [zbeg, zend), a multiple of 2 except at the end
   const int span = (((zend - zbeg + 3) / 4) + 1) & ~1;
@@ -214,9 +200,71 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
   }
 }
 
+__global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) { gemm_small_body(g, blockIdx.x, blockIdx.y, blockIdx.z); }
+
+// Several independent small products in one launch: blockIdx.z = instance * splits + reduction slice.
+// The grid is sized for the largest instance; workgroups outside an instance's tile range leave at once.
+__global__ __launch_bounds__(256) void gemm_small_group_kernel(GemmGroup grp) {
+  const int inst = blockIdx.z / grp.splits, bz = blockIdx.z - inst * grp.splits;
+  const GemmArgs& g = grp.g[inst];
+  if ((int)blockIdx.x * 32 >= g.N || (int)blockIdx.y * 32 >= g.M || bz * g.k_chunk >= g.K) return;
+  gemm_small_body(g, blockIdx.x, blockIdx.y, bz);
+}
+
+GemmArgs gemm_args(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj, float* C, long ldc,
+                   int M, int N, int K, const float* bias, int act, int mode) {
+  return GemmArgs{A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, M, N, K, K, act, mode, a_sk == 1, b_sk == 1};
+}
+
+static int gemm_one(GemmArgs g, hipStream_t st);
+
+int gemm_group(const GemmArgs* gs, int n, hipStream_t st) {
+  if (n <= 0) return HHRL_OK;
+  // the grouped kernel serves latency-bound sizes; anything larger goes through the single-product path
+  int max_m = 0, max_n = 0, max_k = 0;
+  bool small = n <= kGemmGroupMax, reduce_mode = false;
+  for (int i = 0; i < n; ++i) {
+    const GemmArgs& g = gs[i];
+    if ((long)ceil_div(g.M, 32) * ceil_div(g.N, 32) > 512) small = false;
+    if (g.mode == 2) reduce_mode = true;
+    max_m = g.M > max_m ? g.M : max_m;
+    max_n = g.N > max_n ? g.N : max_n;
+    max_k = g.K > max_k ? g.K : max_k;
+  }
+  if (!small || n == 1) {
+    for (int i = 0; i < n; ++i) HHRL_TRY(gemm_one(gs[i], st));
+    return HHRL_OK;
+  }
+  GemmGroup grp;
+  grp.splits = 1;
+  int chunk = 0;
+  if (reduce_mode && max_k > 1024) {
+    grp.splits = ceil_div(max_k, 512) < 8 ? ceil_div(max_k, 512) : 8;
+    chunk = (ceil_div(max_k, grp.splits) + 7) & ~7;
+    grp.splits = ceil_div(max_k, chunk);
+  }
+  double flops = 0.0, bytes = 0.0;
+  for (int i = 0; i < n; ++i) {
+    grp.g[i] = gs[i];
+    grp.g[i].k_chunk = (grp.splits > 1 && gs[i].mode == 2) ? chunk : gs[i].K;
+    flops += 2.0 * gs[i].M * gs[i].N * gs[i].K;
+    bytes += 4.0 * ((double)gs[i].M * gs[i].K + (double)gs[i].K * gs[i].N + (double)gs[i].M * gs[i].N);
+  }
+  dim3 grid(ceil_div(max_n, 32), ceil_div(max_m, 32), n * grp.splits);
+  ProfScope ps("gemm_small_group_kernel", st, flops, bytes);
+  hipLaunchKernelGGL(gemm_small_group_kernel, grid, dim3(256), 0, st, grp);
+  return launch_status("gemm_small_group_kernel");
+}
+
 int gemm(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj, float* C, long ldc,
          int M, int N, int K, const float* bias, int act, int mode, hipStream_t st) {
-  GemmArgs g{A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, M, N, K, K, act, mode, a_sk == 1, b_sk == 1};
+  return gemm_one(gemm_args(A, a_si, a_sk, B, b_sk, b_sj, C, ldc, M, N, K, bias, act, mode), st);
+}
+
+static int gemm_one(GemmArgs g, hipStream_t st) {
+  const float *A = g.A, *B = g.B;
+  (void)A; (void)B;
+  const int M = g.M, N = g.N, K = g.K, mode = g.mode;
   const long tiles32 = (long)ceil_div(M, 32) * ceil_div(N, 32);
   if (tiles32 <= 512) {
     int gz = 1;

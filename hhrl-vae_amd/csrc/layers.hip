@@ -46,6 +46,40 @@ __global__ __launch_bounds__(256) void act_grad_colsum_kernel(const float* __res
   if (ty == 0 && col < N) unsafeAtomicAdd(&db[col], red[t]);
 }
 
+// The same for several layers in one launch (blockIdx.z = layer); rows M shared.
+struct ActGradInst { const float* y; float *dy, *db; int ldy, lddy, N, act, cw; };
+struct ActGradGroup { ActGradInst in[kGemmGroupMax]; };
+__global__ __launch_bounds__(256) void act_grad_colsum_group_kernel(ActGradGroup grp, int M, int rows_per_unit) {
+  __shared__ float red[256];
+  const ActGradInst& g = grp.in[blockIdx.z];
+  const int t = threadIdx.x;
+  const int cw = g.cw, tx = t % cw, ty = t / cw, rp = 256 / cw;
+  const int col = blockIdx.x * cw + tx;
+  const int rows_per_block = rp * rows_per_unit;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(M, r0 + rows_per_block);
+  if (blockIdx.x * cw >= g.N || r0 >= M) return;
+  float s = 0.f;
+  if (col < g.N) {
+    for (int r = r0 + ty; r < r1; r += rp) {
+      float gr = g.dy[(long)r * g.lddy + col];
+      if (g.act != HHRL_ACT_NONE) {
+        gr *= act_grad_from_output(g.y[(long)r * g.ldy + col], g.act);
+        g.dy[(long)r * g.lddy + col] = gr;
+      }
+      s += gr;
+    }
+  }
+  if (g.db == nullptr) return;
+  red[t] = s;
+  __syncthreads();
+  for (int h = rp >> 1; h > 0; h >>= 1) {
+    if (ty < h) red[t] += red[t + h * cw];
+    __syncthreads();
+  }
+  if (ty == 0 && col < g.N) unsafeAtomicAdd(&g.db[col], red[t]);
+}
+
 __global__ void sum_pool_kernel(const float* __restrict__ in, int ldi, float* out, int ldo, int B, int N, int C) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)B * C) return;
@@ -122,6 +156,76 @@ int hhrl_linear_backward(const float* x, int ldx, const float* w, const float* y
   if (dx) HHRL_TRY(gemm(dy, lddy, 1, w, K, 1, dx, lddx, M, K, N, nullptr, HHRL_ACT_NONE, dx_accumulate ? 1 : 0, st));
   if (dw) HHRL_TRY(gemm(dy, 1, lddy, x, ldx, 1, dw, K, N, K, M, nullptr, HHRL_ACT_NONE, 2, st));
   return HHRL_OK;
+}
+
+int hhrl_linear_forward_group(const hhrl_linear_fwd_desc* d, int n, int M, void* stream) {
+  HHRL_REQUIRE(d && n >= 1 && n <= kGemmGroupMax, "linear_forward_group: %d layers (1..%d supported)", n, kGemmGroupMax);
+  HHRL_REQUIRE(M > 0, "linear_forward_group: M=%d", M);
+  GemmArgs g[kGemmGroupMax];
+  for (int i = 0; i < n; ++i) {
+    const hhrl_linear_fwd_desc& l = d[i];
+    HHRL_REQUIRE(l.x && l.w && l.y, "linear_forward_group: layer %d: null pointer", i);
+    HHRL_REQUIRE(l.K > 0 && l.N > 0 && l.ldx >= l.K && l.ldy >= l.N, "linear_forward_group: layer %d: bad shape K=%d N=%d ldx=%d ldy=%d",
+                 i, l.K, l.N, l.ldx, l.ldy);
+    HHRL_REQUIRE(valid_act(l.act), "linear_forward_group: layer %d: bad activation %d", i, l.act);
+    g[i] = gemm_args(l.x, l.ldx, 1, l.w, 1, l.K, l.y, l.ldy, M, l.N, l.K, l.b, l.act, l.accumulate ? 1 : 0);
+  }
+  return gemm_group(g, n, as_stream(stream));
+}
+
+int hhrl_linear_backward_group(const hhrl_linear_bwd_desc* d, int n, int M, void* stream) {
+  HHRL_REQUIRE(d && n >= 1 && n <= kGemmGroupMax, "linear_backward_group: %d layers (1..%d supported)", n, kGemmGroupMax);
+  HHRL_REQUIRE(M > 0, "linear_backward_group: M=%d", M);
+  hipStream_t st = as_stream(stream);
+  ActGradGroup ag;
+  int n_ag = 0, max_n = 0, min_cw = 64;
+  for (int i = 0; i < n; ++i) {
+    const hhrl_linear_bwd_desc& l = d[i];
+    HHRL_REQUIRE(l.dy && l.w, "linear_backward_group: layer %d: null pointer", i);
+    HHRL_REQUIRE(l.K > 0 && l.N > 0 && l.lddy >= l.N, "linear_backward_group: layer %d: bad shape K=%d N=%d lddy=%d", i, l.K, l.N, l.lddy);
+    HHRL_REQUIRE(valid_act(l.act), "linear_backward_group: layer %d: bad activation %d", i, l.act);
+    HHRL_REQUIRE(l.act == HHRL_ACT_NONE || (l.y && l.ldy >= l.N), "linear_backward_group: layer %d: activation gradient needs y", i);
+    HHRL_REQUIRE(!l.dx || l.lddx >= l.K, "linear_backward_group: layer %d: lddx=%d < K=%d", i, l.lddx, l.K);
+    HHRL_REQUIRE(!l.dw || (l.x && l.ldx >= l.K), "linear_backward_group: layer %d: dW needs x with ldx >= K", i);
+    if (l.act != HHRL_ACT_NONE || l.db) {
+      int cw = 64;
+      while (cw > 1 && cw / 2 >= l.N) cw >>= 1;
+      ag.in[n_ag++] = ActGradInst{l.y, l.dy, l.db, l.ldy, l.lddy, l.N, l.act, cw};
+      max_n = l.N > max_n ? l.N : max_n;
+      min_cw = cw < min_cw ? cw : min_cw;
+    }
+  }
+  if (n_ag > 0) {
+    // every workgroup covers (256 / cw) * 16 rows of its layer; the grid is sized for the narrowest column block
+    const int rows_min = (256 / 64) * 16;
+    dim3 grid(ceil_div(max_n, min_cw), ceil_div(M, rows_min), n_ag);
+    ProfScope ps("act_grad_colsum_group_kernel", st, 0.0, 0.0);
+    hipLaunchKernelGGL(act_grad_colsum_group_kernel, grid, dim3(256), 0, st, ag, M, 16);
+    HHRL_TRY(launch_status("act_grad_colsum_group_kernel"));
+  }
+  // input gradients: layers that overwrite their dx first, then the ones that accumulate (they may share a dx)
+  GemmArgs g[kGemmGroupMax];
+  for (int pass = 0; pass < 2; ++pass) {
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+      const hhrl_linear_bwd_desc& l = d[i];
+      if (l.dx && (l.dx_accumulate ? 1 : 0) == pass)
+        g[m++] = gemm_args(l.dy, l.lddy, 1, l.w, l.K, 1, l.dx, l.lddx, M, l.K, l.N, nullptr, HHRL_ACT_NONE, pass);
+    }
+    if (pass == 1) {
+      // accumulating products into one buffer must not run concurrently with each other
+      for (int a = 0; a < m; ++a)
+        for (int b = a + 1; b < m; ++b)
+          HHRL_REQUIRE(g[a].C != g[b].C, "linear_backward_group: two layers accumulate into the same dx");
+    }
+    HHRL_TRY(gemm_group(g, m, st));
+  }
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    const hhrl_linear_bwd_desc& l = d[i];
+    if (l.dw) g[m++] = gemm_args(l.dy, 1, l.lddy, l.x, l.ldx, 1, l.dw, l.K, l.N, l.K, M, nullptr, HHRL_ACT_NONE, 2);
+  }
+  return gemm_group(g, m, st);
 }
 
 int hhrl_sum_pool(const float* in, int ldi, float* out, int ldo, int B, int N, int C, void* stream) {

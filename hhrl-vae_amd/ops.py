@@ -52,6 +52,30 @@ class Lin:
                                              gw, gb, M, self.K, self.N, self.act, _lib.stream_ptr()))
 
 
+def linear_forward_group(items, M: int) -> None:
+    """items: [(Lin, x, ldx, y, ldy)]: independent layers on the same M rows, one launch."""
+    n = len(items)
+    arr = (_lib.LinearFwdDesc * n)()
+    for d, (l, x, ldx, y, ldy) in zip(arr, items):
+        d.x, d.ldx, d.w, d.b, d.y, d.ldy = x, ldx, l.w, l.b, y, ldy
+        d.K, d.N, d.act, d.accumulate = l.K, l.N, l.act, 0
+    check(_lib.load().hhrl_linear_forward_group(arr, n, M, _lib.stream_ptr()))
+
+
+def linear_backward_group(items, M: int, param_grads: bool = True) -> None:
+    """items: [(Lin, x, ldx, y, ldy, dy, lddy, dx, lddx, dx_accumulate)] with the meaning of Lin.bwd;
+    one launch per stage (activation/bias gradient, input gradients, weight gradients)."""
+    n = len(items)
+    arr = (_lib.LinearBwdDesc * n)()
+    for d, (l, x, ldx, y, ldy, dy, lddy, dx, lddx, acc) in zip(arr, items):
+        d.x, d.ldx, d.w, d.y, d.ldy, d.dy, d.lddy = x, ldx, l.w, y, ldy, dy, lddy
+        d.dx, d.lddx, d.dx_accumulate = dx, lddx, acc
+        d.dw = l.gw if param_grads else None
+        d.db = l.gb if param_grads else None
+        d.K, d.N, d.act = l.K, l.N, l.act
+    check(_lib.load().hhrl_linear_backward_group(arr, n, M, _lib.stream_ptr()))
+
+
 LSTM_KEYS = ["lstm_layer.weight_ih_l0", "lstm_layer.weight_hh_l0", "lstm_layer.bias_ih_l0", "lstm_layer.bias_hh_l0",
              "lstm_layer.weight_ih_l0_reverse", "lstm_layer.weight_hh_l0_reverse",
              "lstm_layer.bias_ih_l0_reverse", "lstm_layer.bias_hh_l0_reverse", "fc.weight", "fc.bias"]
@@ -78,6 +102,47 @@ class BiLstm:
     def bwd(self, d_out: int, lddo: int, ws: torch.Tensor, B: int) -> None:
         check(self._lib.hhrl_lstm_backward(self.params, d_out, lddo, self.grads, ws.data_ptr(), B, self.T, self.o,
                                            self.H, _lib.stream_ptr()))
+
+
+def _lstm_descs(items, forward: bool):
+    """items: (BiLstm, a, lda, ws) with a = observations (forward: + out, ldo appended) or d_out."""
+    n = len(items)
+    arr = (_lib.LstmDesc * n)()
+    for d, it in zip(arr, items):
+        l = it[0]
+        d.o = l.o
+        d.params = C.cast(l.params, C.c_void_p)
+        d.grads = C.cast(l.grads, C.c_void_p) if l.grads is not None else None
+        if forward:
+            _, obs, ldobs, out, ldo, ws = it
+            d.obs, d.ldobs, d.out, d.ldo = obs, ldobs, out, ldo
+        else:
+            _, d_out, lddo, ws = it
+            d.d_out, d.lddo = d_out, lddo
+        d.ws = ws.data_ptr()
+    return arr
+
+
+def lstm_forward_group(items, B: int) -> None:
+    """items: [(BiLstm, obs_ptr, ldobs, out_ptr, ldo, workspace)]: LSTM modules sharing T and H,
+    evaluated on B rows each, every stage one launch for the whole group."""
+    lib = _lib.load()
+    T, H = items[0][0].T, items[0][0].H
+    for it in items:
+        if it[0].T != T or it[0].H != H:
+            raise ValueError("grouped LSTMs must share T and H")
+    for i in range(0, len(items), _lib.LSTM_GROUP_MAX):
+        part = items[i:i + _lib.LSTM_GROUP_MAX]
+        check(lib.hhrl_lstm_forward_group(_lstm_descs(part, True), len(part), B, T, H, _lib.stream_ptr()))
+
+
+def lstm_backward_group(items, B: int) -> None:
+    """items: [(BiLstm, d_out_ptr, lddo, workspace)] for modules whose forward ran through their workspace."""
+    lib = _lib.load()
+    T, H = items[0][0].T, items[0][0].H
+    for i in range(0, len(items), _lib.LSTM_GROUP_MAX):
+        part = items[i:i + _lib.LSTM_GROUP_MAX]
+        check(lib.hhrl_lstm_backward_group(_lstm_descs(part, False), len(part), B, T, H, _lib.stream_ptr()))
 
 
 def sum_pool(inp: int, ldi: int, out: int, ldo: int, B: int, N: int, Cc: int) -> None:

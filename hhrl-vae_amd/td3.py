@@ -77,12 +77,24 @@ class ActorNet:
             w = self._work[B] = _ActorWork(self, B, self.dev)
         return w
 
-    def forward(self, B: int, obs: int, ld_obs: int, goal: Optional[int], ld_goal: int, out: int, ld_out: int) -> None:
+    def lstm_item(self, B: int, obs: int, ld_obs: int):
+        """This actor's LSTM evaluation as an entry of a grouped launch (ops.lstm_forward_group)."""
+        w = self.work(B)
+        return (self.lstm, obs, ld_obs, P(w.xin), self.d_in, w.lstm_ws)
+
+    def lstm_bwd_item(self, B: int):
+        w = self.work(B)
+        return (self.lstm, P(w.d_xin), self.d_in, w.lstm_ws)
+
+    def forward(self, B: int, obs: int, ld_obs: int, goal: Optional[int], ld_goal: int, out: int, ld_out: int,
+                lstm_done: bool = False) -> None:
+        """lstm_done: the LSTM feature was already produced by a grouped launch built from lstm_item()."""
         w = self.work(B)
         s = self.stream
         if self.needs_xin:
             if self.lstm is not None:
-                self.lstm.fwd(obs, ld_obs, P(w.xin), self.d_in, w.lstm_ws, B)
+                if not lstm_done:
+                    self.lstm.fwd(obs, ld_obs, P(w.xin), self.d_in, w.lstm_ws, B)
             else:
                 ops.copy2d(obs, ld_obs, P(w.xin), self.d_in, B, s.o)
             if self.fam.goal_dim:
@@ -95,15 +107,17 @@ class ActorNet:
         self.l2.fwd(P(w.h1), self.h[0], P(w.h2), self.h[1], B)
         self.l3.fwd(P(w.h2), self.h[1], out, ld_out, B)
 
-    def backward(self, B: int, out: int, ld_out: int, d_out: int, ld_dout: int) -> None:
+    def backward(self, B: int, out: int, ld_out: int, d_out: int, ld_dout: int, lstm: bool = True) -> None:
         """Gradients of the most recent forward(B, ...) into this actor's flat
-        gradient buffer (added; the caller zeroes it)."""
+        gradient buffer (added; the caller zeroes it).  lstm=False leaves the
+        BPTT to the caller (lstm_bwd_item)."""
         w = self.work(B)
         self.l3.bwd(P(w.h2), self.h[1], out, ld_out, d_out, ld_dout, P(w.d_h2), self.h[1], B)
         self.l2.bwd(P(w.h1), self.h[0], P(w.h2), self.h[1], P(w.d_h2), self.h[1], P(w.d_h1), self.h[0], B)
         if self.lstm is not None:
             self.l1.bwd(w.x, w.ldx, P(w.h1), self.h[0], P(w.d_h1), self.h[0], P(w.d_xin), self.d_in, B)
-            self.lstm.bwd(P(w.d_xin), self.d_in, w.lstm_ws, B)
+            if lstm:
+                self.lstm.bwd(P(w.d_xin), self.d_in, w.lstm_ws, B)
         else:
             self.l1.bwd(w.x, w.ldx, P(w.h1), self.h[0], P(w.d_h1), self.h[0], None, 0, B)
 
@@ -117,6 +131,7 @@ class _CriticWork:
         self.b1, self.b2, self.q2 = e(B, h0), e(B, h1), e(B, 1)
         self.d_q1, self.d_q2 = e(B, 1), e(B, 1)
         self.d_a2, self.d_a1 = e(B, h1), e(B, h0)
+        self.d_b2, self.d_b1 = e(B, h1), e(B, h0)
         self.d_xu = e(B, net.D)
         self.lstm_ws = [l.workspace(B, dev) if l is not None else None for l in net.lstms]
 
@@ -166,6 +181,25 @@ class CriticNet:
         else:
             ops.copy2d(o_ptr, o_ld, P(w.xu, col), self.D, B, s.o)
 
+    def feature_item(self, k: int, B: int, o_ptr: int, o_ld: int):
+        """Stream k's LSTM evaluation as an entry of a grouped launch (streams without an LSTM: None)."""
+        if self.lstms[k] is None:
+            return None
+        w = self.work(B)
+        return (self.lstms[k], o_ptr, o_ld, P(w.xu, self.feat_cols[k]), self.D, w.lstm_ws[k])
+
+    def lstm_bwd_item(self, k: int, B: int):
+        if self.lstms[k] is None:
+            return None
+        w = self.work(B)
+        return (self.lstms[k], P(w.d_xu, self.feat_cols[k]), self.D, w.lstm_ws[k])
+
+    def raw_features(self, B: int, obs: Sequence[Tuple[int, int]]) -> None:
+        """Streams without an LSTM: the observation itself is the feature."""
+        for k, (o_ptr, o_ld) in enumerate(obs):
+            if self.lstms[k] is None:
+                self.feature(k, B, o_ptr, o_ld)
+
     def set_goal(self, B: int, goal: Optional[int], ld_goal: int) -> None:
         if self.fam.goal_dim:
             w = self.work(B)
@@ -185,14 +219,15 @@ class CriticNet:
     def heads(self, B: int, q1_only: bool = False) -> None:
         w = self.work(B)
         h0, h1 = self.h
-        self.l1.fwd(P(w.xu), self.D, P(w.a1), h0, B)
-        self.l2.fwd(P(w.a1), h0, P(w.a2), h1, B)
-        self.l3.fwd(P(w.a2), h1, P(w.q1), 1, B)
         if q1_only:
+            self.l1.fwd(P(w.xu), self.D, P(w.a1), h0, B)
+            self.l2.fwd(P(w.a1), h0, P(w.a2), h1, B)
+            self.l3.fwd(P(w.a2), h1, P(w.q1), 1, B)
             return
-        self.l4.fwd(P(w.xu), self.D, P(w.b1), h0, B)
-        self.l5.fwd(P(w.b1), h0, P(w.b2), h1, B)
-        self.l6.fwd(P(w.b2), h1, P(w.q2), 1, B)
+        # the two heads are independent: layer k of both in one launch
+        ops.linear_forward_group([(self.l1, P(w.xu), self.D, P(w.a1), h0), (self.l4, P(w.xu), self.D, P(w.b1), h0)], B)
+        ops.linear_forward_group([(self.l2, P(w.a1), h0, P(w.a2), h1), (self.l5, P(w.b1), h0, P(w.b2), h1)], B)
+        ops.linear_forward_group([(self.l3, P(w.a2), h1, P(w.q1), 1), (self.l6, P(w.b2), h1, P(w.q2), 1)], B)
 
     def lstm_backward(self, k: int, B: int) -> None:
         """BPTT of stream k's LSTM from its columns of w.d_xu (independent of the other streams)."""
@@ -208,15 +243,19 @@ class CriticNet:
         h0, h1 = self.h
         has_lstm = any(l is not None for l in self.lstms)
         need_dxu = (not param_grads) or has_lstm
-        self.l3.bwd(P(w.a2), h1, None, 0, P(w.d_q1), 1, P(w.d_a2), h1, B, param_grads=param_grads)
-        self.l2.bwd(P(w.a1), h0, P(w.a2), h1, P(w.d_a2), h1, P(w.d_a1), h0, B, param_grads=param_grads)
-        self.l1.bwd(P(w.xu), self.D, P(w.a1), h0, P(w.d_a1), h0, P(w.d_xu) if need_dxu else None, self.D, B,
-                    param_grads=param_grads)
+        dxu = P(w.d_xu) if need_dxu else None
         if both_heads:
-            self.l6.bwd(P(w.b2), h1, None, 0, P(w.d_q2), 1, P(w.d_a2), h1, B, param_grads=param_grads)
-            self.l5.bwd(P(w.b1), h0, P(w.b2), h1, P(w.d_a2), h1, P(w.d_a1), h0, B, param_grads=param_grads)
-            self.l4.bwd(P(w.xu), self.D, P(w.b1), h0, P(w.d_a1), h0, P(w.d_xu) if need_dxu else None, self.D, B,
-                        dx_accumulate=1, param_grads=param_grads)
+            # layer k of both heads per stage; the two first layers add up in d_xu (head 2 accumulates)
+            ops.linear_backward_group([(self.l3, P(w.a2), h1, None, 0, P(w.d_q1), 1, P(w.d_a2), h1, 0),
+                                       (self.l6, P(w.b2), h1, None, 0, P(w.d_q2), 1, P(w.d_b2), h1, 0)], B, param_grads)
+            ops.linear_backward_group([(self.l2, P(w.a1), h0, P(w.a2), h1, P(w.d_a2), h1, P(w.d_a1), h0, 0),
+                                       (self.l5, P(w.b1), h0, P(w.b2), h1, P(w.d_b2), h1, P(w.d_b1), h0, 0)], B, param_grads)
+            ops.linear_backward_group([(self.l1, P(w.xu), self.D, P(w.a1), h0, P(w.d_a1), h0, dxu, self.D, 0),
+                                       (self.l4, P(w.xu), self.D, P(w.b1), h0, P(w.d_b1), h0, dxu, self.D, 1)], B, param_grads)
+        else:
+            self.l3.bwd(P(w.a2), h1, None, 0, P(w.d_q1), 1, P(w.d_a2), h1, B, param_grads=param_grads)
+            self.l2.bwd(P(w.a1), h0, P(w.a2), h1, P(w.d_a2), h1, P(w.d_a1), h0, B, param_grads=param_grads)
+            self.l1.bwd(P(w.xu), self.D, P(w.a1), h0, P(w.d_a1), h0, dxu, self.D, B, param_grads=param_grads)
         if param_grads and lstms:
             for k in range(len(self.lstms)):
                 self.lstm_backward(k, B)
@@ -443,49 +482,58 @@ class TD3Learner:
         # -- target value (no gradient): algorithm.py:1329-1337 / 785-796
         ct, cw_t = self.critic_target, self.critic_target.work(B)
 
+        n_str = len(fam.streams)
+        c, cw = self.critic, self.critic.work(B)
+        # every LSTM that depends only on the minibatch goes into one grouped evaluation: the target actors'
+        # and the target critic's on the next observations, the critic's on the current ones
+        items = [a.lstm_item(B, next_obs[k][0], W) for k, a in enumerate(self.actor_targets) if a.lstm is not None]
+        items += [ct.feature_item(k, B, next_obs[k][0], W) for k in range(n_str)]
+        items += [c.feature_item(k, B, obs[k][0], W) for k in range(n_str)]
+        self._lstm_forward(items, B)
+        ct.raw_features(B, next_obs)
+        c.raw_features(B, obs)
+
         def target_action(k):
             def run():
-                self.actor_targets[k].forward(B, next_obs[k][0], W, next_goal, W, P(pi[k]), fam.a_dims[k])
+                self.actor_targets[k].forward(B, next_obs[k][0], W, next_goal, W, P(pi[k]), fam.a_dims[k], lstm_done=True)
                 check(lib.hhrl_td3_smooth_action(P(pi[k]), fam.a_dims[k], P(noise[k]), P(cw_t.xu, ct.act_cols[k]), ct.D, B,
                                                  fam.a_dims[k], _lib.stream_ptr()))
             return run
-        n_str = len(fam.streams)
-        self._parallel([target_action(k) for k in range(len(self.actors))] +
-                       [(lambda k=k: ct.feature(k, B, next_obs[k][0], W)) for k in range(n_str)])
+        self._parallel([target_action(k) for k in range(len(self.actors))])
         ct.set_goal(B, next_goal, W)
         ct.heads(B)
         check(lib.hhrl_td3_target_q(P(cw_t.q1), P(cw_t.q2), R(self.col_reward), W, fam.gamma, P(y), B, sp))
 
         # -- critic step: :1341-1350 / 799-808
-        c, cw = self.critic, self.critic.work(B)
         c.opt.zero_grad()
         self._loss.zero_()
-        self._parallel([(lambda k=k: c.feature(k, B, obs[k][0], W)) for k in range(n_str)])
         c.set_goal(B, goal, W)
         c.set_actions(B, R(self.col_act), W)
         c.heads(B)
         check(lib.hhrl_twin_mse(P(cw.q1), P(cw.q2), P(y), inv_n, P(self._loss), P(cw.d_q1), P(cw.d_q2), B, sp))
         c.backward(B, both_heads=True, param_grads=True, lstms=False)
-        self._parallel([(lambda k=k: c.lstm_backward(k, B)) for k in range(n_str)])
+        self._lstm_backward([c.lstm_bwd_item(k, B) for k in range(n_str)], B)
         self._allreduce(c.opt.g)
         c.opt.step_dev()
 
         # -- delayed policy step: :1353-1366 / 811-838
         if policy:
-            branches = []
-            if any(l is not None for l in c.lstms):   # LSTM features under the updated critic weights
-                branches += [(lambda k=k: c.feature(k, B, obs[k][0], W)) for k in range(n_str)]
+            # LSTM features under the updated critic weights, and every actor's LSTM, in one grouped evaluation
+            items = [c.feature_item(k, B, obs[k][0], W) for k in range(n_str)]
+            items += [a.lstm_item(B, obs[j][0], W) for j, a in enumerate(self.actors) if a.lstm is not None]
+            self._lstm_forward(items, B)
             # joint action written straight into the critic input
-            branches += [(lambda j=j, a=a: a.forward(B, obs[j][0], W, goal, W, P(cw.xu, c.act_cols[j]), c.D))
-                         for j, a in enumerate(self.actors)]
-            self._parallel(branches)
+            self._parallel([(lambda j=j, a=a: a.forward(B, obs[j][0], W, goal, W, P(cw.xu, c.act_cols[j]), c.D, lstm_done=True))
+                            for j, a in enumerate(self.actors)])
             for n, i in enumerate(order):
                 a = self.actors[i]
                 c.heads(B, q1_only=True)
                 ops.fill(P(cw.d_q1), B, -inv_n)       # d(-mean Q1)/dQ1
                 c.backward(B, both_heads=False, param_grads=False)
                 a.opt.zero_grad()
-                a.backward(B, P(cw.xu, c.act_cols[i]), c.D, P(cw.d_xu, c.act_cols[i]), c.D)
+                a.backward(B, P(cw.xu, c.act_cols[i]), c.D, P(cw.d_xu, c.act_cols[i]), c.D, lstm=False)
+                if a.lstm is not None:
+                    self._lstm_backward([a.lstm_bwd_item(B)], B)
                 self._allreduce(a.opt.g)
                 a.opt.step_dev()
                 if n + 1 < len(order):                # later actors see this actor's new policy
@@ -493,6 +541,22 @@ class TD3Learner:
             ops.polyak(self.critic_target.params, self.critic.params, fam.tau)
             for a, t in zip(self.actors, self.actor_targets):
                 ops.polyak(t.params, a.params, fam.tau)
+
+    @staticmethod
+    def _by_shape(items):
+        groups: Dict[Tuple[int, int], list] = {}
+        for it in items:
+            if it is not None:
+                groups.setdefault((it[0].T, it[0].H), []).append(it)
+        return groups.values()
+
+    def _lstm_forward(self, items, B: int) -> None:
+        for grp in self._by_shape(items):
+            ops.lstm_forward_group(grp, B)
+
+    def _lstm_backward(self, items, B: int) -> None:
+        for grp in self._by_shape(items):
+            ops.lstm_backward_group(grp, B)
 
     def _allreduce(self, g: FlatBuffer) -> None:
         if self.group is not None:

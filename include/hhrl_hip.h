@@ -60,6 +60,33 @@ int hhrl_linear_backward(const float* x, int ldx, const float* w,
                          float* dw, float* db, int M, int K, int N, int act,
                          void* stream);
 
+/* Several independent dense layers on the same M rows in ONE launch per stage
+ * (the twin Q heads l1/l4, l2/l5, l3/l6 of the critics, algorithm.py:206-221,
+ * 381-400, 650-672, 1236-1254): a batch-64 update is bound by the number of
+ * launches.  Same meaning as the arguments of hhrl_linear_forward/backward.
+ * Backward runs the stages activation-gradient + bias gradient, input
+ * gradients (overwriting layers first, accumulating layers in a second launch:
+ * an accumulating layer may add to a dx that an overwriting layer of the same
+ * call wrote), weight gradients. */
+#define HHRL_LINEAR_GROUP_MAX 16
+typedef struct {
+  const float* x; int ldx;
+  const float* w; const float* b;
+  float* y; int ldy;
+  int K, N, act, accumulate;
+} hhrl_linear_fwd_desc;
+typedef struct {
+  const float* x; int ldx;
+  const float* w;
+  const float* y; int ldy;
+  float* dy; int lddy;
+  float* dx; int lddx; int dx_accumulate;
+  float* dw; float* db;
+  int K, N, act;
+} hhrl_linear_bwd_desc;
+int hhrl_linear_forward_group(const hhrl_linear_fwd_desc* layers, int n, int M, void* stream);
+int hhrl_linear_backward_group(const hhrl_linear_bwd_desc* layers, int n, int M, void* stream);
+
 /* ------------------------------------------------------------ data movement
  * out[b, c] = sum_n in[(b*N+n), c]          (torch.sum(x, dim=-2), algorithm.py:42;
  *                                            also the gradient of the latent repeat, :101) */
@@ -158,6 +185,27 @@ int hhrl_lstm_forward(const float* obs, int ldobs, const float* const* params, f
  * receives nothing: its input state is zero).  No gradient w.r.t. obs. */
 int hhrl_lstm_backward(const float* const* params, const float* d_out, int lddo,
                        float* const* grads, float* ws, int B, int T, int o, int H, void* stream);
+
+/* The same two operations for a GROUP of independent LSTM modules that share
+ * B, T and H (the per-stream LSTMs of a critic, `self.lstm[k]` at
+ * algorithm.py:366-371, 630-637; the actors' and targets' LSTMs evaluated on
+ * the same minibatch): every stage is one launch for the whole group, which is
+ * what bounds a batch-64 update.  Fields not used by a direction may be null. */
+#define HHRL_LSTM_GROUP_MAX 16
+typedef struct {
+  const float* obs;            /* forward: [B, T*o] rows, leading dimension ldobs */
+  int ldobs;
+  int o;                       /* observation width per time step */
+  const float* const* params;  /* 10 device pointers, as above */
+  float* const* grads;         /* backward: 10 device pointers, gradients are ADDED */
+  float* out;                  /* forward: [B,H], leading dimension ldo */
+  int ldo;
+  const float* d_out;          /* backward: [B,H], leading dimension lddo (equal for all instances) */
+  int lddo;
+  float* ws;                   /* hhrl_lstm_workspace_floats(B,T,o,H) floats per instance */
+} hhrl_lstm_desc;
+int hhrl_lstm_forward_group(const hhrl_lstm_desc* descs, int n, int B, int T, int H, void* stream);
+int hhrl_lstm_backward_group(const hhrl_lstm_desc* descs, int n, int B, int T, int H, void* stream);
 
 /* --------------------------------------------------------------- optimiser
  * torch.optim.Adam.step with default betas/eps on one flat buffer
