@@ -28,6 +28,14 @@ class LstmDesc(C.Structure):
 LSTM_GROUP_MAX = 16
 
 
+class CopyDesc(C.Structure):
+    """hhrl_copy_desc of include/hhrl_hip.h."""
+    _fields_ = [("inp", _P), ("ldi", _I), ("out", _P), ("ldo", _I), ("C", _I)]
+
+
+COPY_GROUP_MAX = 32
+
+
 class LinearFwdDesc(C.Structure):
     """hhrl_linear_fwd_desc of include/hhrl_hip.h."""
     _fields_ = [("x", _P), ("ldx", _I), ("w", _P), ("b", _P), ("y", _P), ("ldy", _I),
@@ -51,6 +59,7 @@ SIGNATURES = {
     "hhrl_sum_pool": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     "hhrl_broadcast_rows": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     "hhrl_copy2d": (_I, [_P, _I, _P, _I, _I, _I, _P]),
+    "hhrl_copy2d_group": (_I, [_P, _I, _I, _P]),
     "hhrl_fill": (_I, [_P, _L, _F, _P]),
     "hhrl_vae_reparam": (_I, [_P, _P, _P, _I, _I, _P]),
     "hhrl_vae_elbo": (_I, [_P, _P, _P, _F, _P, _P, _I, _I, _I, _P]),

@@ -106,6 +106,17 @@ __global__ void copy2d_kernel(const float* __restrict__ in, int ldi, float* out,
   out[r * ldo + c] = in[r * ldi + c];
 }
 
+struct CopyInst { const float* in; float* out; int ldi, ldo, C; };
+struct CopyGroup { CopyInst in[HHRL_COPY_GROUP_MAX]; };
+__global__ void copy2d_group_kernel(CopyGroup grp, int M) {
+  const CopyInst& g = grp.in[blockIdx.y];
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)M * g.C) return;
+  const int c = idx % g.C;
+  const long r = idx / g.C;
+  g.out[r * g.ldo + c] = g.in[r * g.ldi + c];
+}
+
 __global__ void fill_kernel(float* p, long n, float v) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < n) p[idx] = v;
@@ -250,6 +261,25 @@ int hhrl_copy2d(const float* in, int ldi, float* out, int ldo, int M, int C, voi
   ProfScope ps("copy2d_kernel", as_stream(stream), 0.0, 8.0 * M * C);
   hipLaunchKernelGGL(copy2d_kernel, dim3(ceil_div((long)M * C, 256)), dim3(256), 0, as_stream(stream), in, ldi, out, ldo, M, C);
   return launch_status("copy2d_kernel");
+}
+
+int hhrl_copy2d_group(const hhrl_copy_desc* d, int n, int M, void* stream) {
+  HHRL_REQUIRE(d && n >= 1 && n <= HHRL_COPY_GROUP_MAX, "copy2d_group: %d blocks (1..%d supported)", n, HHRL_COPY_GROUP_MAX);
+  HHRL_REQUIRE(M > 0, "copy2d_group: M=%d", M);
+  CopyGroup g;
+  int cmax = 0;
+  double bytes = 0.0;
+  for (int i = 0; i < n; ++i) {
+    HHRL_REQUIRE(d[i].in && d[i].out, "copy2d_group: block %d: null pointer", i);
+    HHRL_REQUIRE(d[i].C > 0 && d[i].ldi >= d[i].C && d[i].ldo >= d[i].C, "copy2d_group: block %d: bad shape C=%d ldi=%d ldo=%d", i,
+                 d[i].C, d[i].ldi, d[i].ldo);
+    g.in[i] = CopyInst{d[i].in, d[i].out, d[i].ldi, d[i].ldo, d[i].C};
+    cmax = d[i].C > cmax ? d[i].C : cmax;
+    bytes += 8.0 * M * d[i].C;
+  }
+  ProfScope ps("copy2d_group_kernel", as_stream(stream), 0.0, bytes);
+  hipLaunchKernelGGL(copy2d_group_kernel, dim3(ceil_div((long)M * cmax, 256), n), dim3(256), 0, as_stream(stream), g, M);
+  return launch_status("copy2d_group_kernel");
 }
 
 int hhrl_fill(float* p, long n, float value, void* stream) {

@@ -157,6 +157,27 @@ def copy2d(inp: int, ldi: int, out: int, ldo: int, M: int, Cc: int) -> None:
     check(_lib.load().hhrl_copy2d(inp, ldi, out, ldo, M, Cc, _lib.stream_ptr()))
 
 
+class CopyQueue:
+    """Collects [M, C] block copies that do not depend on each other and issues them as one launch."""
+
+    def __init__(self, M: int):
+        self.M = M
+        self.items = []
+
+    def add(self, inp: int, ldi: int, out: int, ldo: int, Cc: int) -> None:
+        self.items.append((inp, ldi, out, ldo, Cc))
+
+    def flush(self) -> None:
+        lib = _lib.load()
+        for i in range(0, len(self.items), _lib.COPY_GROUP_MAX):
+            part = self.items[i:i + _lib.COPY_GROUP_MAX]
+            arr = (_lib.CopyDesc * len(part))()
+            for d, (inp, ldi, out, ldo, Cc) in zip(arr, part):
+                d.inp, d.ldi, d.out, d.ldo, d.C = inp, ldi, out, ldo, Cc
+            check(lib.hhrl_copy2d_group(arr, len(part), self.M, _lib.stream_ptr()))
+        self.items = []
+
+
 def fill(p: int, n: int, value: float) -> None:
     check(_lib.load().hhrl_fill(p, n, value, _lib.stream_ptr()))
 

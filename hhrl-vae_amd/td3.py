@@ -86,23 +86,44 @@ class ActorNet:
         w = self.work(B)
         return (self.lstm, P(w.d_xin), self.d_in, w.lstm_ws)
 
-    def forward(self, B: int, obs: int, ld_obs: int, goal: Optional[int], ld_goal: int, out: int, ld_out: int,
-                lstm_done: bool = False) -> None:
-        """lstm_done: the LSTM feature was already produced by a grouped launch built from lstm_item()."""
+    def stage_inputs(self, cq: "ops.CopyQueue", B: int, obs: int, ld_obs: int, goal: Optional[int], ld_goal: int) -> None:
+        """Queues the copies that build the MLP input from replay-row columns (raw observation when
+        there is no LSTM, goal)."""
         w = self.work(B)
         s = self.stream
         if self.needs_xin:
-            if self.lstm is not None:
-                if not lstm_done:
-                    self.lstm.fwd(obs, ld_obs, P(w.xin), self.d_in, w.lstm_ws, B)
-            else:
-                ops.copy2d(obs, ld_obs, P(w.xin), self.d_in, B, s.o)
+            if self.lstm is None:
+                cq.add(obs, ld_obs, P(w.xin), self.d_in, s.o)
             if self.fam.goal_dim:
-                ops.copy2d(goal, ld_goal, P(w.xin, s.feat), self.d_in, B, self.fam.goal_dim)
-            x, ldx = P(w.xin), self.d_in
-        else:
-            x, ldx = obs, ld_obs
-        w.x, w.ldx = x, ldx
+                cq.add(goal, ld_goal, P(w.xin, s.feat), self.d_in, self.fam.goal_dim)
+
+    def bind_input(self, B: int, obs: int, ld_obs: int) -> None:
+        w = self.work(B)
+        w.x, w.ldx = (P(w.xin), self.d_in) if self.needs_xin else (obs, ld_obs)
+
+    def level_item(self, level: int, B: int, out: int, ld_out: int):
+        """Layer `level` (1..3) of the MLP as an entry of ops.linear_forward_group (after bind_input)."""
+        w = self.work(B)
+        if level == 1:
+            return (self.l1, w.x, w.ldx, P(w.h1), self.h[0])
+        if level == 2:
+            return (self.l2, P(w.h1), self.h[0], P(w.h2), self.h[1])
+        return (self.l3, P(w.h2), self.h[1], out, ld_out)
+
+    def forward(self, B: int, obs: int, ld_obs: int, goal: Optional[int], ld_goal: int, out: int, ld_out: int,
+                lstm_done: bool = False, inputs_done: bool = False) -> None:
+        """lstm_done: the LSTM feature was already produced by a grouped launch built from lstm_item();
+        inputs_done: stage_inputs() was already flushed for these rows."""
+        w = self.work(B)
+        if self.lstm is not None and not lstm_done:
+            self.lstm.fwd(obs, ld_obs, P(w.xin), self.d_in, w.lstm_ws, B)
+        if not inputs_done:
+            cq = ops.CopyQueue(B)
+            self.stage_inputs(cq, B, obs, ld_obs, goal, ld_goal)
+            if cq.items:
+                cq.flush()
+        self.bind_input(B, obs, ld_obs)
+        x, ldx = w.x, w.ldx
         self.l1.fwd(x, ldx, P(w.h1), self.h[0], B)
         self.l2.fwd(P(w.h1), self.h[0], P(w.h2), self.h[1], B)
         self.l3.fwd(P(w.h2), self.h[1], out, ld_out, B)
@@ -194,11 +215,18 @@ class CriticNet:
         w = self.work(B)
         return (self.lstms[k], P(w.d_xu, self.feat_cols[k]), self.D, w.lstm_ws[k])
 
-    def raw_features(self, B: int, obs: Sequence[Tuple[int, int]]) -> None:
-        """Streams without an LSTM: the observation itself is the feature."""
+    def stage_inputs(self, cq: "ops.CopyQueue", B: int, obs: Sequence[Tuple[int, int]], goal: Optional[int], ld_goal: int,
+                     actions: Optional[int] = None, ld_act: int = 0) -> None:
+        """Queues the copies of replay-row columns into the head input: raw observations of streams
+        without an LSTM, the goal, and (if given) the stored joint action."""
+        w = self.work(B)
         for k, (o_ptr, o_ld) in enumerate(obs):
             if self.lstms[k] is None:
-                self.feature(k, B, o_ptr, o_ld)
+                cq.add(o_ptr, o_ld, P(w.xu, self.feat_cols[k]), self.D, self.fam.streams[k].o)
+        if self.fam.goal_dim:
+            cq.add(goal, ld_goal, P(w.xu, self.goal_col), self.D, self.fam.goal_dim)
+        if actions is not None:
+            cq.add(actions, ld_act, P(w.xu, self.act_col), self.D, self.fam.act_dim)
 
     def set_goal(self, B: int, goal: Optional[int], ld_goal: int) -> None:
         if self.fam.goal_dim:
@@ -340,8 +368,6 @@ class TD3Learner:
         self._graphs: Dict[tuple, "torch.cuda.CUDAGraph"] = {}
         self._seen: Dict[tuple, int] = {}
         self.use_graph = bool(use_graph)
-        self._capturing = False
-        self._side_streams: List["torch.cuda.Stream"] = []
         # column offsets inside a replay row
         f = fam
         pos = 0
@@ -424,12 +450,8 @@ class TD3Learner:
         elif self.use_graph and self.group is None and self._seen.get(key, 0) >= 2:
             graph = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
-            self._capturing = True
-            try:
-                with torch.cuda.graph(graph):
-                    self._update_body(st, B, policy, order)
-            finally:
-                self._capturing = False
+            with torch.cuda.graph(graph):
+                self._update_body(st, B, policy, order)
             self._graphs[key] = graph
             graph.replay()
         else:
@@ -444,28 +466,6 @@ class TD3Learner:
             for s in self.actor_scheds:
                 s.step()
         self.last_critic_loss = self._loss
-
-    def _parallel(self, fns) -> None:
-        """Runs independent kernel sequences.  While a graph is being captured
-        each sequence goes to a side stream forked from, and joined back into,
-        the capture stream, so the graph holds them as parallel branches (the
-        per-stream LSTMs of a manager are small and leave most CUs idle on
-        their own); otherwise they simply run in turn."""
-        if not self._capturing or len(fns) < 2:
-            for fn in fns:
-                fn()
-            return
-        main = torch.cuda.current_stream()
-        while len(self._side_streams) < len(fns) - 1:
-            self._side_streams.append(torch.cuda.Stream(device=self.device))
-        fns[0]()
-        for sd, fn in zip(self._side_streams, fns[1:]):
-            sd.wait_stream(main)
-        for sd, fn in zip(self._side_streams, fns[1:]):
-            with torch.cuda.stream(sd):
-                fn()
-        for sd, _ in zip(self._side_streams, fns[1:]):
-            main.wait_stream(sd)
 
     def _update_body(self, st: "TD3Learner._Static", B: int, policy: bool, order: Sequence[int]) -> None:
         """The kernel sequence of one update (no host-side state changes)."""
@@ -490,25 +490,33 @@ class TD3Learner:
         items += [ct.feature_item(k, B, next_obs[k][0], W) for k in range(n_str)]
         items += [c.feature_item(k, B, obs[k][0], W) for k in range(n_str)]
         self._lstm_forward(items, B)
-        ct.raw_features(B, next_obs)
-        c.raw_features(B, obs)
+        # every piece of a network input that is a plain column range of the sampled rows: one launch
+        cq = ops.CopyQueue(B)
+        for k, a in enumerate(self.actor_targets):
+            a.stage_inputs(cq, B, next_obs[k][0], W, next_goal, W)
+        ct.stage_inputs(cq, B, next_obs, next_goal, W)
+        c.stage_inputs(cq, B, obs, goal, W, R(self.col_act), W)
+        if policy:
+            for j, a in enumerate(self.actors):
+                a.stage_inputs(cq, B, obs[j][0], W, goal, W)
+        if cq.items:
+            cq.flush()
 
-        def target_action(k):
-            def run():
-                self.actor_targets[k].forward(B, next_obs[k][0], W, next_goal, W, P(pi[k]), fam.a_dims[k], lstm_done=True)
-                check(lib.hhrl_td3_smooth_action(P(pi[k]), fam.a_dims[k], P(noise[k]), P(cw_t.xu, ct.act_cols[k]), ct.D, B,
-                                                 fam.a_dims[k], _lib.stream_ptr()))
-            return run
-        self._parallel([target_action(k) for k in range(len(self.actors))])
-        ct.set_goal(B, next_goal, W)
+        # target policies: layer k of every actor in one launch, then the smoothing noise
+        for k, a in enumerate(self.actor_targets):
+            a.bind_input(B, next_obs[k][0], W)
+        for level in (1, 2, 3):
+            ops.linear_forward_group([a.level_item(level, B, P(pi[k]), fam.a_dims[k])
+                                      for k, a in enumerate(self.actor_targets)], B)
+        for k in range(len(self.actors)):
+            check(lib.hhrl_td3_smooth_action(P(pi[k]), fam.a_dims[k], P(noise[k]), P(cw_t.xu, ct.act_cols[k]), ct.D, B,
+                                             fam.a_dims[k], sp))
         ct.heads(B)
         check(lib.hhrl_td3_target_q(P(cw_t.q1), P(cw_t.q2), R(self.col_reward), W, fam.gamma, P(y), B, sp))
 
         # -- critic step: :1341-1350 / 799-808
         c.opt.zero_grad()
         self._loss.zero_()
-        c.set_goal(B, goal, W)
-        c.set_actions(B, R(self.col_act), W)
         c.heads(B)
         check(lib.hhrl_twin_mse(P(cw.q1), P(cw.q2), P(y), inv_n, P(self._loss), P(cw.d_q1), P(cw.d_q2), B, sp))
         c.backward(B, both_heads=True, param_grads=True, lstms=False)
@@ -522,9 +530,12 @@ class TD3Learner:
             items = [c.feature_item(k, B, obs[k][0], W) for k in range(n_str)]
             items += [a.lstm_item(B, obs[j][0], W) for j, a in enumerate(self.actors) if a.lstm is not None]
             self._lstm_forward(items, B)
-            # joint action written straight into the critic input
-            self._parallel([(lambda j=j, a=a: a.forward(B, obs[j][0], W, goal, W, P(cw.xu, c.act_cols[j]), c.D, lstm_done=True))
-                            for j, a in enumerate(self.actors)])
+            # joint action written straight into the critic input: layer k of every actor in one launch
+            for j, a in enumerate(self.actors):
+                a.bind_input(B, obs[j][0], W)
+            for level in (1, 2, 3):
+                ops.linear_forward_group([a.level_item(level, B, P(cw.xu, c.act_cols[j]), c.D)
+                                          for j, a in enumerate(self.actors)], B)
             for n, i in enumerate(order):
                 a = self.actors[i]
                 c.heads(B, q1_only=True)
@@ -537,7 +548,7 @@ class TD3Learner:
                 self._allreduce(a.opt.g)
                 a.opt.step_dev()
                 if n + 1 < len(order):                # later actors see this actor's new policy
-                    a.forward(B, obs[i][0], W, goal, W, P(cw.xu, c.act_cols[i]), c.D)
+                    a.forward(B, obs[i][0], W, goal, W, P(cw.xu, c.act_cols[i]), c.D, inputs_done=True)
             ops.polyak(self.critic_target.params, self.critic.params, fam.tau)
             for a, t in zip(self.actors, self.actor_targets):
                 ops.polyak(t.params, a.params, fam.tau)

@@ -96,6 +96,11 @@ int hhrl_sum_pool(const float* in, int ldi, float* out, int ldo, int B, int N, i
 int hhrl_broadcast_rows(const float* in, int ldi, float* out, int ldo, int B, int N, int C, void* stream);
 /* out[m, c] = in[m, c] for a [M,C] block    (torch.cat pieces, algorithm.py:71, 212, 383, 652, 1207, 1238) */
 int hhrl_copy2d(const float* in, int ldi, float* out, int ldo, int M, int C, void* stream);
+/* Several such copies of M rows each in one launch (every torch.cat piece of an update that
+ * depends only on the sampled rows). */
+#define HHRL_COPY_GROUP_MAX 32
+typedef struct { const float* in; int ldi; float* out; int ldo; int C; } hhrl_copy_desc;
+int hhrl_copy2d_group(const hhrl_copy_desc* blocks, int n, int M, void* stream);
 /* p[i] = value */
 int hhrl_fill(float* p, long n, float value, void* stream);
 
