@@ -142,9 +142,13 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     group = None
-    if world > 1:
+    # HHRL_FORCE_DIST=1 exercises the data-parallel path (process group, flat all-reduce) with one rank
+    if world > 1 or os.environ.get("HHRL_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
         group = dist.group.WORLD
 
@@ -157,7 +161,7 @@ def main() -> None:
     gcount = B * N * world
 
     def barrier():
-        if world > 1:
+        if group is not None:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -170,7 +174,7 @@ def main() -> None:
         enc.learn(x, sync=False, global_count=gcount)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if group is not None:
         import torch.distributed as dist
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -244,7 +248,7 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_vae(B, N, g)
         print(json.dumps(out))
-    if world > 1:
+    if group is not None:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

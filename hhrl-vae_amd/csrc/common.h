@@ -65,12 +65,15 @@ struct AdamK {
 };
 AdamK make_adam_k(double lr, double beta1, double beta2, double eps, int step, double grad_scale);
 
+// Every operation is spelled out with a rounding intrinsic, so that the compiler cannot contract the
+// update differently at different call sites: the stand-alone optimizer kernels and the reduction that
+// applies Adam in place give the same bits.
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamK& k) {
-  g *= k.gscale;
-  m = m + k.one_minus_b1 * (g - m);                 // exp_avg.lerp_(grad, 1-beta1)
-  v = v * k.beta2 + k.one_minus_b2 * g * g;         // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1-beta2)
-  const float denom = sqrtf(v) / k.bc2_sqrt + k.eps;
-  p = p - k.step_size * (m / denom);
+  g = __fmul_rn(g, k.gscale);
+  m = __fmaf_rn(k.one_minus_b1, __fsub_rn(g, m), m);                               // exp_avg.lerp_(grad, 1-beta1)
+  v = __fmaf_rn(k.one_minus_b2, __fmul_rn(g, g), __fmul_rn(v, k.beta2));           // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1-beta2)
+  const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), k.bc2_sqrt), k.eps);
+  p = __fsub_rn(p, __fmul_rn(k.step_size, __fdiv_rn(m, denom)));
 }
 
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

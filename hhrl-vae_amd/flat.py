@@ -50,7 +50,10 @@ class FlatBuffer:
 
     def __init__(self, layout: Layout, device):
         self.layout = layout
-        self.data = torch.zeros(layout.size, dtype=torch.float32, device=device)
+        # `full` = the buffer plus a tail of ALIGN scratch floats right behind it: a data-parallel step
+        # puts its loss there so that gradient and loss travel in one all-reduce
+        self.full = torch.zeros(layout.size + ALIGN, dtype=torch.float32, device=device)
+        self.data = self.full[:layout.size]
         self.views: Dict[str, torch.Tensor] = {}
         for name, shp in layout.shapes.items():
             off = layout.offsets[name]
@@ -63,6 +66,10 @@ class FlatBuffer:
     @property
     def base_ptr(self) -> int:
         return self._base
+
+    @property
+    def tail_ptr(self) -> int:
+        return self._base + 4 * self.layout.size
 
     def __getitem__(self, name: str) -> torch.Tensor:
         return self.views[name]

@@ -194,7 +194,8 @@ class Encoder:
         return self._loss
 
     # ------------------------------------------------------------ training
-    def loss_and_grads(self, data, eps=None, recon_count: Optional[int] = None, _adam: bool = False) -> torch.Tensor:
+    def loss_and_grads(self, data, eps=None, recon_count: Optional[int] = None, _adam: bool = False,
+                       _loss_to_tail: bool = False) -> torch.Tensor:
         """Forward + ELBO + backward into the flat gradient buffer (zeroed
         first).  Returns the loss as a 0-dim device tensor (no sync).
         recon_count: divisor of the squared-error sum (default B*N; the global
@@ -221,16 +222,18 @@ class Encoder:
                 ws = self._fused_ws[(B, N)] = ops.dev_zeros(n, device=self.device)
             scale = 1.0 / float(recon_count if recon_count is not None else B * N)
             loss = self._next_loss_slot()
+            # data-parallel: the loss lands right behind the gradient so that one all-reduce carries both
+            loss_ptr = self.opt.g.tail_ptr if _loss_to_tail else P(loss)
             if _adam:
                 # forward, backward and the optimizer step in one call (single device)
                 o = self.opt
                 o.step_count += 1
                 check(lib.hhrl_vae_learn_step(self.params.base_ptr, o.g.base_ptr, o.m.base_ptr, o.v.base_ptr,
                                               self._offsets, self.layout.size, P(x), P(eps), B, N, g, scale,
-                                              o.lr, o.beta1, o.beta2, o.eps, o.step_count, P(loss), P(ws), st))
+                                              o.lr, o.beta1, o.beta2, o.eps, o.step_count, loss_ptr, P(ws), st))
             else:
                 check(lib.hhrl_vae_train_step(self.params.base_ptr, self.opt.g.base_ptr, self._offsets,
-                                              self.layout.size, P(x), P(eps), B, N, g, scale, P(loss), P(ws), st))
+                                              self.layout.size, P(x), P(eps), B, N, g, scale, loss_ptr, P(ws), st))
             self._keep = (x, eps)
             return loss[0]
         w = self._ws(B, N)
@@ -280,9 +283,16 @@ class Encoder:
             x = self._to_device(data)
             if global_count is None:
                 global_count = hdist.global_count(int(x.shape[0] * x.shape[1]), self.group, self.device)
-            loss = self.loss_and_grads(x, eps, recon_count=global_count)
-            hdist.allreduce_sum_(self.opt.g.data, self.group)           # one flat bucket, SUM
-            loss = hdist.allreduce_sum_(loss.clone(), self.group)
+            g = self.opt.g
+            if self.fused:
+                loss = self.loss_and_grads(x, eps, recon_count=global_count, _loss_to_tail=True)
+                hdist.allreduce_sum_(g.full, self.group)                # one flat bucket: gradient + loss, SUM
+                self._loss.copy_(g.full[self.layout.size:self.layout.size + 1])
+                loss = self._loss[0]
+            else:
+                loss = self.loss_and_grads(x, eps, recon_count=global_count)
+                hdist.allreduce_sum_(g.data, self.group)
+                loss = hdist.allreduce_sum_(loss.clone(), self.group)
             self.opt.step()                                             # :106
         return float(loss.item()) if sync else loss
 

@@ -1,0 +1,66 @@
+"""The data-parallel code path on a real GPU with a one-rank RCCL group: the
+process group, the flat gradient(+loss) all-reduce and the separate Adam
+launch must reproduce the single-device step bit for bit (a one-rank SUM is
+the identity).  The two-rank arithmetic is covered on CPU by test_dist_gloo."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gen
+import hhrl_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def group():
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29571")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield dist.group.WORLD
+    if created:
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+
+
+def test_vae_one_rank_group_matches_single_device(group):
+    from hhrl_vae_amd.algorithm import Encoder
+    g, B, N = 4, 257, 7
+    init = {k: torch.from_numpy(v) for k, v in gen.gen_state(O.vae_param_shapes(g), 11).items()}
+    a, b = Encoder(2, g, device="cuda:0"), Encoder(2, g, device="cuda:0", group=group)
+    a.load_state_dict(init)
+    b.load_state_dict(init)
+    for step in range(3):
+        x = torch.from_numpy(gen.gen_lanes(B, N, 40 + step)).cuda()
+        eps = torch.randn(B, g, generator=torch.Generator().manual_seed(step)).cuda()
+        la = a.learn(x, eps=eps)
+        lb = b.learn(x, eps=eps)
+        assert la == lb
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    assert a.opt.step_count == b.opt.step_count == 3
+
+
+def test_td3_one_rank_group_matches_single_device(group):
+    from hhrl_vae_amd.algorithm import WorkerTD3
+    cfg = gen.cav_cfg(cap=256)
+    a, b = WorkerTD3(cfg, device="cuda:0", seed=5), WorkerTD3(cfg, device="cuda:0", seed=5, group=group)
+    rows = np.random.RandomState(2).uniform(0, 1, size=(256, a.fam.row_width))
+    for net in (a, b):
+        net.memory[:] = rows
+        net.pointer = 256
+    rs = np.random.RandomState(3)
+    for step in range(4):
+        idx = rs.randint(0, 256, size=a.batch_size)
+        noise = [rs.standard_normal((a.batch_size, d)).astype(np.float32) for d in a.fam.a_dims]
+        a.learn(indices=idx, noise=noise)
+        b.learn(indices=idx, noise=noise)
+    for (na, sa), (nb, sb) in zip(a.state_dicts().items(), b.state_dicts().items()):
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), (na, k)
