@@ -36,6 +36,19 @@ class CopyDesc(C.Structure):
 COPY_GROUP_MAX = 32
 
 
+class Mlp3Desc(C.Structure):
+    """hhrl_mlp3_desc of include/hhrl_hip.h."""
+    _fields_ = [("x", _P), ("ldx", _I), ("K0", _I),
+                ("w1", _P), ("b1", _P), ("w2", _P), ("b2", _P), ("w3", _P), ("b3", _P),
+                ("N3", _I), ("act3", _I), ("h1", _P), ("h2", _P), ("y", _P), ("ldy", _I),
+                ("dy", _P), ("lddy", _I), ("dy_const", _F),
+                ("gw1", _P), ("gb1", _P), ("gw2", _P), ("gb2", _P), ("gw3", _P), ("gb3", _P),
+                ("dx", _P), ("lddx", _I)]
+
+
+MLP3_GROUP_MAX = 8
+
+
 class LinearFwdDesc(C.Structure):
     """hhrl_linear_fwd_desc of include/hhrl_hip.h."""
     _fields_ = [("x", _P), ("ldx", _I), ("w", _P), ("b", _P), ("y", _P), ("ldy", _I),
@@ -56,6 +69,9 @@ SIGNATURES = {
     "hhrl_linear_backward": (_I, [_P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P]),
     "hhrl_linear_forward_group": (_I, [_P, _I, _I, _P]),
     "hhrl_linear_backward_group": (_I, [_P, _I, _I, _P]),
+    "hhrl_mlp3_supported": (_I, [_I, _I, _I, _I]),
+    "hhrl_mlp3_forward_group": (_I, [_P, _I, _I, _P]),
+    "hhrl_mlp3_backward_group": (_I, [_P, _I, _I, _P]),
     "hhrl_sum_pool": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     "hhrl_broadcast_rows": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     "hhrl_copy2d": (_I, [_P, _I, _P, _I, _I, _I, _P]),

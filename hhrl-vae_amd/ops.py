@@ -76,6 +76,46 @@ def linear_backward_group(items, M: int, param_grads: bool = True) -> None:
     check(_lib.load().hhrl_linear_backward_group(arr, n, M, _lib.stream_ptr()))
 
 
+class Mlp3:
+    """Three consecutive dense layers (ReLU, ReLU, act3) bound to the fused kernels."""
+
+    def __init__(self, l1: Lin, l2: Lin, l3: Lin):
+        self.l = (l1, l2, l3)
+        self.K0, self.N3, self.act3 = l1.K, l3.N, l3.act
+
+    @staticmethod
+    def supported(l1: Lin, l2: Lin, l3: Lin) -> bool:
+        if l1.act != ACT_RELU or l2.act != ACT_RELU or l2.K != l1.N or l3.K != l2.N:
+            return False
+        return bool(_lib.load().hhrl_mlp3_supported(l1.K, l1.N, l2.N, l3.N))
+
+    def desc(self, d, x: int, ldx: int, y: int, ldy: int, h1: Optional[int], h2: Optional[int]) -> None:
+        l1, l2, l3 = self.l
+        d.x, d.ldx, d.K0 = x, ldx, self.K0
+        d.w1, d.b1, d.w2, d.b2, d.w3, d.b3 = l1.w, l1.b, l2.w, l2.b, l3.w, l3.b
+        d.N3, d.act3 = self.N3, self.act3
+        d.h1, d.h2, d.y, d.ldy = h1, h2, y, ldy
+
+    def grads(self, d, dy: Optional[int], lddy: int, dy_const: float, param_grads: bool, dx: Optional[int], lddx: int) -> None:
+        l1, l2, l3 = self.l
+        d.dy, d.lddy, d.dy_const = dy, lddy, dy_const
+        if param_grads:
+            d.gw1, d.gb1, d.gw2, d.gb2, d.gw3, d.gb3 = l1.gw, l1.gb, l2.gw, l2.gb, l3.gw, l3.gb
+        d.dx, d.lddx = dx, lddx
+
+
+def mlp3_descs(n: int):
+    return (_lib.Mlp3Desc * n)()
+
+
+def mlp3_forward_group(descs, M: int) -> None:
+    check(_lib.load().hhrl_mlp3_forward_group(descs, len(descs), M, _lib.stream_ptr()))
+
+
+def mlp3_backward_group(descs, M: int) -> None:
+    check(_lib.load().hhrl_mlp3_backward_group(descs, len(descs), M, _lib.stream_ptr()))
+
+
 LSTM_KEYS = ["lstm_layer.weight_ih_l0", "lstm_layer.weight_hh_l0", "lstm_layer.bias_ih_l0", "lstm_layer.bias_hh_l0",
              "lstm_layer.weight_ih_l0_reverse", "lstm_layer.weight_hh_l0_reverse",
              "lstm_layer.bias_ih_l0_reverse", "lstm_layer.bias_hh_l0_reverse", "fc.weight", "fc.bias"]

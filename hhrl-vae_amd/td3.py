@@ -69,6 +69,8 @@ class ActorNet:
         self.l1 = Lin(self.params, g, "l1", ACT_RELU)
         self.l2 = Lin(self.params, g, "l2", ACT_RELU)
         self.l3 = Lin(self.params, g, "l3", ACT_TANH)          # max_action == 1
+        # 128-wide networks without an LSTM run as one fused launch per direction
+        self.mlp3 = ops.Mlp3(self.l1, self.l2, self.l3) if self.lstm is None and ops.Mlp3.supported(self.l1, self.l2, self.l3) else None
         self._work: Dict[int, _ActorWork] = {}
 
     def work(self, B: int) -> _ActorWork:
@@ -110,6 +112,11 @@ class ActorNet:
             return (self.l2, P(w.h1), self.h[0], P(w.h2), self.h[1])
         return (self.l3, P(w.h2), self.h[1], out, ld_out)
 
+    def fused_desc(self, d, B: int, out: int, ld_out: int) -> None:
+        """Fills one hhrl_mlp3_desc with this actor's forward pass (after bind_input)."""
+        w = self.work(B)
+        self.mlp3.desc(d, w.x, w.ldx, out, ld_out, P(w.h1), P(w.h2))
+
     def forward(self, B: int, obs: int, ld_obs: int, goal: Optional[int], ld_goal: int, out: int, ld_out: int,
                 lstm_done: bool = False, inputs_done: bool = False) -> None:
         """lstm_done: the LSTM feature was already produced by a grouped launch built from lstm_item();
@@ -124,6 +131,11 @@ class ActorNet:
                 cq.flush()
         self.bind_input(B, obs, ld_obs)
         x, ldx = w.x, w.ldx
+        if self.mlp3 is not None:
+            d = ops.mlp3_descs(1)
+            self.fused_desc(d[0], B, out, ld_out)
+            ops.mlp3_forward_group(d, B)
+            return
         self.l1.fwd(x, ldx, P(w.h1), self.h[0], B)
         self.l2.fwd(P(w.h1), self.h[0], P(w.h2), self.h[1], B)
         self.l3.fwd(P(w.h2), self.h[1], out, ld_out, B)
@@ -133,6 +145,12 @@ class ActorNet:
         gradient buffer (added; the caller zeroes it).  lstm=False leaves the
         BPTT to the caller (lstm_bwd_item)."""
         w = self.work(B)
+        if self.mlp3 is not None:
+            d = ops.mlp3_descs(1)
+            self.fused_desc(d[0], B, out, ld_out)
+            self.mlp3.grads(d[0], d_out, ld_dout, 0.0, True, None, 0)
+            ops.mlp3_backward_group(d, B)
+            return
         self.l3.bwd(P(w.h2), self.h[1], out, ld_out, d_out, ld_dout, P(w.d_h2), self.h[1], B)
         self.l2.bwd(P(w.h1), self.h[0], P(w.h2), self.h[1], P(w.d_h2), self.h[1], P(w.d_h1), self.h[0], B)
         if self.lstm is not None:
@@ -185,6 +203,10 @@ class CriticNet:
         L = lambda n, a: Lin(self.params, g, n, a)
         self.l1, self.l2, self.l3 = L("l1", ACT_RELU), L("l2", ACT_RELU), L("l3", ACT_NONE)
         self.l4, self.l5, self.l6 = L("l4", ACT_RELU), L("l5", ACT_RELU), L("l6", ACT_NONE)
+        # 128-wide heads without LSTM streams run as one fused launch per direction (both heads side by side)
+        self.mlp3 = None
+        if all(l is None for l in self.lstms) and ops.Mlp3.supported(self.l1, self.l2, self.l3):
+            self.mlp3 = (ops.Mlp3(self.l1, self.l2, self.l3), ops.Mlp3(self.l4, self.l5, self.l6))
         self._work: Dict[int, _CriticWork] = {}
 
     def work(self, B: int) -> _CriticWork:
@@ -247,6 +269,13 @@ class CriticNet:
     def heads(self, B: int, q1_only: bool = False) -> None:
         w = self.work(B)
         h0, h1 = self.h
+        if self.mlp3 is not None:
+            d = ops.mlp3_descs(1 if q1_only else 2)
+            self.mlp3[0].desc(d[0], P(w.xu), self.D, P(w.q1), 1, P(w.a1), P(w.a2))
+            if not q1_only:
+                self.mlp3[1].desc(d[1], P(w.xu), self.D, P(w.q2), 1, P(w.b1), P(w.b2))
+            ops.mlp3_forward_group(d, B)
+            return
         if q1_only:
             self.l1.fwd(P(w.xu), self.D, P(w.a1), h0, B)
             self.l2.fwd(P(w.a1), h0, P(w.a2), h1, B)
@@ -263,15 +292,28 @@ class CriticNet:
         if self.lstms[k] is not None:
             self.lstms[k].bwd(P(w.d_xu, self.feat_cols[k]), self.D, w.lstm_ws[k], B)
 
-    def backward(self, B: int, both_heads: bool, param_grads: bool, lstms: bool = True) -> None:
+    def backward(self, B: int, both_heads: bool, param_grads: bool, lstms: bool = True,
+                 dq_const: Optional[float] = None) -> None:
         """Back-propagates w.d_q1 (and w.d_q2) to w.d_xu; with param_grads also
         into the critic's gradient buffer (its LSTMs too unless lstms=False:
-        the caller then runs lstm_backward per stream)."""
+        the caller then runs lstm_backward per stream).  dq_const: dL/dQ1 is
+        this constant for every row (the gradient of -mean Q1) instead of w.d_q1."""
         w = self.work(B)
         h0, h1 = self.h
         has_lstm = any(l is not None for l in self.lstms)
         need_dxu = (not param_grads) or has_lstm
         dxu = P(w.d_xu) if need_dxu else None
+        if self.mlp3 is not None and not (both_heads and need_dxu):
+            d = ops.mlp3_descs(2 if both_heads else 1)
+            self.mlp3[0].desc(d[0], P(w.xu), self.D, P(w.q1), 1, P(w.a1), P(w.a2))
+            self.mlp3[0].grads(d[0], None if dq_const is not None else P(w.d_q1), 1, dq_const or 0.0, param_grads, dxu, self.D)
+            if both_heads:
+                self.mlp3[1].desc(d[1], P(w.xu), self.D, P(w.q2), 1, P(w.b1), P(w.b2))
+                self.mlp3[1].grads(d[1], P(w.d_q2), 1, 0.0, param_grads, None, 0)
+            ops.mlp3_backward_group(d, B)
+            return
+        if dq_const is not None:
+            ops.fill(P(w.d_q1), B, dq_const)
         if both_heads:
             # layer k of both heads per stage; the two first layers add up in d_xu (head 2 accumulates)
             ops.linear_backward_group([(self.l3, P(w.a2), h1, None, 0, P(w.d_q1), 1, P(w.d_a2), h1, 0),
@@ -505,9 +547,7 @@ class TD3Learner:
         # target policies: layer k of every actor in one launch, then the smoothing noise
         for k, a in enumerate(self.actor_targets):
             a.bind_input(B, next_obs[k][0], W)
-        for level in (1, 2, 3):
-            ops.linear_forward_group([a.level_item(level, B, P(pi[k]), fam.a_dims[k])
-                                      for k, a in enumerate(self.actor_targets)], B)
+        self._actors_forward(self.actor_targets, B, [(P(pi[k]), fam.a_dims[k]) for k in range(len(self.actors))])
         for k in range(len(self.actors)):
             check(lib.hhrl_td3_smooth_action(P(pi[k]), fam.a_dims[k], P(noise[k]), P(cw_t.xu, ct.act_cols[k]), ct.D, B,
                                              fam.a_dims[k], sp))
@@ -533,14 +573,11 @@ class TD3Learner:
             # joint action written straight into the critic input: layer k of every actor in one launch
             for j, a in enumerate(self.actors):
                 a.bind_input(B, obs[j][0], W)
-            for level in (1, 2, 3):
-                ops.linear_forward_group([a.level_item(level, B, P(cw.xu, c.act_cols[j]), c.D)
-                                          for j, a in enumerate(self.actors)], B)
+            self._actors_forward(self.actors, B, [(P(cw.xu, c.act_cols[j]), c.D) for j in range(len(self.actors))])
             for n, i in enumerate(order):
                 a = self.actors[i]
                 c.heads(B, q1_only=True)
-                ops.fill(P(cw.d_q1), B, -inv_n)       # d(-mean Q1)/dQ1
-                c.backward(B, both_heads=False, param_grads=False)
+                c.backward(B, both_heads=False, param_grads=False, dq_const=-inv_n)       # d(-mean Q1)/dQ1
                 a.opt.zero_grad()
                 a.backward(B, P(cw.xu, c.act_cols[i]), c.D, P(cw.d_xu, c.act_cols[i]), c.D, lstm=False)
                 if a.lstm is not None:
@@ -552,6 +589,19 @@ class TD3Learner:
             ops.polyak(self.critic_target.params, self.critic.params, fam.tau)
             for a, t in zip(self.actors, self.actor_targets):
                 ops.polyak(t.params, a.params, fam.tau)
+
+    @staticmethod
+    def _actors_forward(nets, B: int, outs) -> None:
+        """The MLPs of several actors on bound inputs: one fused launch when every network is covered
+        by the three-layer kernels, else layer k of every actor per launch."""
+        if all(a.mlp3 is not None for a in nets):
+            d = ops.mlp3_descs(len(nets))
+            for k, a in enumerate(nets):
+                a.fused_desc(d[k], B, outs[k][0], outs[k][1])
+            ops.mlp3_forward_group(d, B)
+            return
+        for level in (1, 2, 3):
+            ops.linear_forward_group([a.level_item(level, B, outs[k][0], outs[k][1]) for k, a in enumerate(nets)], B)
 
     @staticmethod
     def _by_shape(items):

@@ -169,6 +169,31 @@ int hhrl_td3_target_q(const float* q1, const float* q2, const float* r, int ldr,
 int hhrl_twin_mse(const float* q1, const float* q2, const float* y, float inv_n, float* loss,
                   float* dq1, float* dq2, int B, void* stream);
 
+/* ------------------------------------------------- three dense layers, fused
+ * y = act3(W3 relu(W2 relu(W1 x + b1) + b2) + b3) as one launch per direction for a GROUP of
+ * networks on the same M rows, for hidden widths 128/128 (WorkerActor / WorkerCritic,
+ * algorithm.py:1187-1258; both Q heads of a critic, or a network and its target, are separate
+ * entries of one group).  hhrl_mlp3_supported tells whether a shape is covered (K0 <= 64,
+ * H1 = H2 = 128, N3 <= 32); other shapes go through hhrl_linear_*.
+ * Forward writes y and, when h1/h2 are given, the two hidden activations [M,128] that the backward
+ * call reads.  Backward: dy is dL/dy (null: every element equals dy_const, the gradient of a mean);
+ * the six gradient pointers are all given (gradients are ADDED) or all null (input gradient only);
+ * dx, when given, receives dL/dx. */
+#define HHRL_MLP3_GROUP_MAX 8
+typedef struct {
+  const float* x; int ldx; int K0;
+  const float *w1, *b1, *w2, *b2, *w3, *b3;
+  int N3, act3;
+  float *h1, *h2;
+  float* y; int ldy;
+  const float* dy; int lddy; float dy_const;
+  float *gw1, *gb1, *gw2, *gb2, *gw3, *gb3;
+  float* dx; int lddx;
+} hhrl_mlp3_desc;
+int hhrl_mlp3_supported(int K0, int H1, int H2, int N3);
+int hhrl_mlp3_forward_group(const hhrl_mlp3_desc* nets, int n, int M, void* stream);
+int hhrl_mlp3_backward_group(const hhrl_mlp3_desc* nets, int n, int M, void* stream);
+
 /* -------------------------------------------------------------------- LSTM
  * Bidirectional one-layer LSTM over a window of T steps, last time index only,
  * followed by Linear(2H -> H)             (LSTM.forward, algorithm.py:152-156).
