@@ -179,7 +179,7 @@ def test_vae_elementwise(env):
     decd, datad = dec.detach().to(dev), data.to(dev)          # keep device operands referenced while kernels run
     L.check(lib.hhrl_vae_elbo(decd.data_ptr(), datad.data_ptr(), mld.data_ptr(), 1.0 / (B * N),
                               loss.data_ptr(), ddec.data_ptr(), B, N, gd, st))
-    scaled_close("loss", loss.cpu().numpy(), [float(recon + kl)])
+    scaled_close("loss", loss.cpu().numpy(), [float((recon + kl).detach())])
     scaled_close("ddec", ddec.cpu().numpy(), dec.grad.numpy())
     dml = torch.zeros(B, 2 * gd, device=dev)
     dzd = dz.to(dev)
@@ -250,3 +250,173 @@ def test_lstm_forward_backward(env, B, T, o, H):
     for n, p, gdev in zip(names + ["fc.weight", "fc.bias"], ps, gd):
         want = p.grad if p.grad is not None else torch.zeros_like(p)
         scaled_close("grad " + n, gdev.cpu().numpy(), want.numpy(), atol_rel=1e-5)
+
+
+# ------------------------------------------------------------------ grouped / fused entry points
+@pytest.mark.parametrize("B,T,H,obs_dims", [(64, 10, 128, (13, 13, 25)), (33, 4, 32, (5, 29)), (7, 3, 8, (4, 6, 3))])
+def test_lstm_group_matches_torch(env, B, T, H, obs_dims):
+    """hhrl_lstm_forward_group / _backward_group: several LSTM modules with different observation
+    widths in one call, each against torch.nn.LSTM + Linear."""
+    lib, L, dev = env
+    torch.manual_seed(B + T + H + sum(obs_dims))
+    n = len(obs_dims)
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l0_reverse", "weight_hh_l0_reverse",
+             "bias_ih_l0_reverse", "bias_hh_l0_reverse"]
+    descs = (L.LstmDesc * n)()
+    keep, refs = [], []
+    lddo = H + 5
+    for i, o in enumerate(obs_dims):
+        ref = torch.nn.LSTM(o, H, 1, batch_first=True, bidirectional=True)
+        fc = torch.nn.Linear(2 * H, H)
+        ld = T * o + 1 + i
+        obs = torch.randn(B, ld)
+        out = fc(ref(obs[:, :T * o].reshape(B, T, o))[0][:, -1, :])
+        dout = torch.randn(B, lddo)
+        out.backward(dout[:, :H])
+        ps = [getattr(ref, k) for k in names] + [fc.weight, fc.bias]
+        pd = [p.detach().to(dev).contiguous() for p in ps]
+        gd = [torch.zeros_like(p) for p in pd]
+        parr = (C.c_void_p * 10)(*[p.data_ptr() for p in pd])
+        garr = (C.c_void_p * 10)(*[p.data_ptr() for p in gd])
+        ws = torch.empty(lib.hhrl_lstm_workspace_floats(B, T, o, H), device=dev)
+        od = torch.zeros(B, H + 2, device=dev)
+        obsd, doutd = obs.to(dev), dout.to(dev)
+        d = descs[i]
+        d.obs, d.ldobs, d.o = obsd.data_ptr(), ld, o
+        d.params, d.grads = C.cast(parr, C.c_void_p), C.cast(garr, C.c_void_p)
+        d.out, d.ldo, d.d_out, d.lddo, d.ws = od.data_ptr(), H + 2, doutd.data_ptr(), lddo, ws.data_ptr()
+        keep.append((pd, gd, parr, garr, ws, od, obsd, doutd))
+        refs.append((out.detach(), ps))
+    st = L.stream_ptr()
+    L.check(lib.hhrl_lstm_forward_group(descs, n, B, T, H, st))
+    L.check(lib.hhrl_lstm_backward_group(descs, n, B, T, H, st))
+    for i in range(n):
+        out, ps = refs[i]
+        scaled_close("out[%d]" % i, keep[i][5][:, :H].cpu().numpy(), out.numpy(), atol_rel=5e-6)
+        for k, p, gdev in zip(names + ["fc.weight", "fc.bias"], ps, keep[i][1]):
+            want = p.grad if p.grad is not None else torch.zeros_like(p)
+            scaled_close("grad[%d] %s" % (i, k), gdev.cpu().numpy(), want.numpy(), atol_rel=1e-5)
+
+
+def test_lstm_group_argument_errors(env):
+    lib, L, dev = env
+    descs = (L.LstmDesc * 1)()
+    assert lib.hhrl_lstm_forward_group(descs, 0, 4, 2, 8, None) != 0
+    assert lib.hhrl_lstm_forward_group(descs, 17, 4, 2, 8, None) != 0
+    assert lib.hhrl_lstm_forward_group(descs, 1, 4, 2, 8, None) != 0          # null pointers inside the descriptor
+    assert b"null" in lib.hhrl_last_error()
+
+
+@pytest.mark.parametrize("M", [64, 37, 1024])
+def test_linear_groups_match_single_calls(env, M):
+    """hhrl_linear_forward_group / _backward_group against one hhrl_linear_* call per layer."""
+    lib, L, dev = env
+    g = torch.Generator().manual_seed(M)
+    shapes = [(18, 128, 1), (18, 128, 1), (393, 512, 1), (128, 1, 0), (300, 4, 2)]      # (K, N, act)
+    n = len(shapes)
+    fd, bd = (L.LinearFwdDesc * n)(), (L.LinearBwdDesc * n)()
+    keep = []
+    st = L.stream_ptr()
+    dxs = torch.zeros(M, 18, device=dev)                       # layers 0 and 1 share an input gradient (second accumulates)
+    for i, (K, N, act) in enumerate(shapes):
+        t = lambda *s: torch.randn(*s, generator=g).to(dev)
+        x, w, b, dy = t(M, K + 2), t(N, K) / K ** 0.5, t(N), t(M, N)
+        y1, y2 = torch.zeros(M, N + 1, device=dev), torch.zeros(M, N + 1, device=dev)
+        L.check(lib.hhrl_linear_forward(x.data_ptr(), K + 2, w.data_ptr(), b.data_ptr(), y1.data_ptr(), N + 1, M, K, N, act, 0, st))
+        dy1, dy2 = dy.clone(), dy.clone()
+        dx1 = torch.zeros(M, K, device=dev)
+        dx2 = dxs if i < 2 else torch.zeros(M, K, device=dev)
+        dw1, dw2, db1, db2 = (torch.zeros(N, K, device=dev), torch.zeros(N, K, device=dev), torch.zeros(N, device=dev),
+                              torch.zeros(N, device=dev))
+        L.check(lib.hhrl_linear_backward(x.data_ptr(), K + 2, w.data_ptr(), y1.data_ptr(), N + 1, dy1.data_ptr(), N, dx1.data_ptr(), K, 0,
+                                         dw1.data_ptr(), db1.data_ptr(), M, K, N, act, st))
+        f, bw = fd[i], bd[i]
+        f.x, f.ldx, f.w, f.b, f.y, f.ldy, f.K, f.N, f.act, f.accumulate = x.data_ptr(), K + 2, w.data_ptr(), b.data_ptr(), y2.data_ptr(), N + 1, K, N, act, 0
+        bw.x, bw.ldx, bw.w, bw.y, bw.ldy, bw.dy, bw.lddy = x.data_ptr(), K + 2, w.data_ptr(), y2.data_ptr(), N + 1, dy2.data_ptr(), N
+        bw.dx, bw.lddx, bw.dx_accumulate, bw.dw, bw.db, bw.K, bw.N, bw.act = dx2.data_ptr(), K, 1 if i == 1 else 0, dw2.data_ptr(), db2.data_ptr(), K, N, act
+        keep.append((x, w, b, y1, y2, dy1, dy2, dx1, dx2, dw1, dw2, db1, db2))
+    L.check(lib.hhrl_linear_forward_group(fd, n, M, st))
+    L.check(lib.hhrl_linear_backward_group(bd, n, M, st))
+    for i, (x, w, b, y1, y2, dy1, dy2, dx1, dx2, dw1, dw2, db1, db2) in enumerate(keep):
+        scaled_close("y[%d]" % i, y2.cpu().numpy(), y1.cpu().numpy())
+        scaled_close("dw[%d]" % i, dw2.cpu().numpy(), dw1.cpu().numpy(), atol_rel=1e-5)
+        scaled_close("db[%d]" % i, db2.cpu().numpy(), db1.cpu().numpy(), atol_rel=1e-5)
+        if i >= 2:
+            scaled_close("dx[%d]" % i, dx2.cpu().numpy(), dx1.cpu().numpy(), atol_rel=1e-5)
+    scaled_close("dx[0]+dx[1]", dxs.cpu().numpy(), (keep[0][7] + keep[1][7]).cpu().numpy(), atol_rel=1e-5)
+
+
+def test_copy2d_group(env):
+    lib, L, dev = env
+    M = 70
+    src = torch.randn(M, 40, device=dev)
+    dst = torch.zeros(M, 30, device=dev)
+    blocks = [(0, 5, 3), (10, 0, 2), (20, 12, 11), (39, 29, 1)]            # (source column, destination column, width)
+    arr = (L.CopyDesc * len(blocks))()
+    for d, (sc, dc, w) in zip(arr, blocks):
+        d.inp, d.ldi, d.out, d.ldo, d.C = src.data_ptr() + 4 * sc, 40, dst.data_ptr() + 4 * dc, 30, w
+    L.check(lib.hhrl_copy2d_group(arr, len(blocks), M, L.stream_ptr()))
+    want = torch.zeros(M, 30, device=dev)
+    for sc, dc, w in blocks:
+        want[:, dc:dc + w] = src[:, sc:sc + w]
+    assert torch.equal(dst, want)
+    assert lib.hhrl_copy2d_group(arr, 0, M, None) != 0
+
+
+@pytest.mark.parametrize("M,K0,N3,act3", [(64, 17, 1, 2), (64, 18, 1, 0), (37, 64, 32, 3), (4096, 11, 4, 2), (1, 1, 1, 0)])
+def test_mlp3_fused_matches_torch(env, M, K0, N3, act3):
+    """hhrl_mlp3_forward_group / _backward_group (two networks side by side) against torch autograd:
+    parameter gradients, input gradient, and the constant-upstream-gradient form."""
+    lib, L, dev = env
+    assert lib.hhrl_mlp3_supported(K0, 128, 128, N3) == 1
+    assert lib.hhrl_mlp3_supported(K0, 400, 300, N3) == 0 and lib.hhrl_mlp3_supported(65, 128, 128, N3) == 0
+    g = torch.Generator().manual_seed(M + K0 + N3)
+    n = 2
+    descs = (L.Mlp3Desc * n)()
+    keep, refs = [], []
+    ldx, ldy = K0 + 3, N3 + 2
+    for i in range(n):
+        r = lambda *s: torch.randn(*s, generator=g)
+        x = r(M, ldx)
+        ws = [r(128, K0) / K0 ** 0.5, r(128), r(128, 128) / 128 ** 0.5, r(128), r(N3, 128) / 128 ** 0.5, r(N3)]
+        dy = r(M, N3)
+        xt = x[:, :K0].clone().requires_grad_(True)
+        wt = [w.clone().requires_grad_(True) for w in ws]
+        y = _act(F.linear(F.relu(F.linear(F.relu(F.linear(xt, wt[0], wt[1])), wt[2], wt[3])), wt[4], wt[5]), act3)
+        const = i == 1                                   # second network: dL/dy is a constant (gradient of a mean)
+        (y.sum() * -0.25 if const else (y * dy).sum()).backward()
+        xd, dyd = x.to(dev), dy.to(dev).contiguous()
+        wd = [w.to(dev).contiguous() for w in ws]
+        gd = [torch.zeros_like(w) for w in wd]
+        h1, h2 = torch.empty(M, 128, device=dev), torch.empty(M, 128, device=dev)
+        yd = torch.full((M, ldy), 7.0, device=dev)
+        dxd = torch.zeros(M, K0 + 1, device=dev)
+        d = descs[i]
+        d.x, d.ldx, d.K0 = xd.data_ptr(), ldx, K0
+        d.w1, d.b1, d.w2, d.b2, d.w3, d.b3 = [w.data_ptr() for w in wd]
+        d.N3, d.act3, d.h1, d.h2, d.y, d.ldy = N3, act3, h1.data_ptr(), h2.data_ptr(), yd.data_ptr(), ldy
+        d.dy, d.lddy, d.dy_const = (None, 0, -0.25) if const else (dyd.data_ptr(), N3, 0.0)
+        d.gw1, d.gb1, d.gw2, d.gb2, d.gw3, d.gb3 = [t.data_ptr() for t in gd]
+        d.dx, d.lddx = dxd.data_ptr(), K0 + 1
+        keep.append((xd, dyd, wd, gd, h1, h2, yd, dxd))
+        refs.append((y.detach(), xt.grad, [w.grad for w in wt]))
+    st = L.stream_ptr()
+    L.check(lib.hhrl_mlp3_forward_group(descs, n, M, st))
+    L.check(lib.hhrl_mlp3_backward_group(descs, n, M, st))
+    for i in range(n):
+        y, dx, gws = refs[i]
+        xd, dyd, wd, gd, h1, h2, yd, dxd = keep[i]
+        scaled_close("y[%d]" % i, yd[:, :N3].cpu().numpy(), y.numpy(), atol_rel=5e-6)
+        assert torch.all(yd[:, N3:] == 7.0), "forward wrote outside its column slice"
+        scaled_close("dx[%d]" % i, dxd[:, :K0].cpu().numpy(), dx.numpy(), atol_rel=1e-5)
+        assert torch.all(dxd[:, K0:] == 0.0)
+        for k, (got, want) in enumerate(zip(gd, gws)):
+            scaled_close("grad[%d][%d]" % (i, k), got.cpu().numpy(), want.numpy(), atol_rel=1e-5)
+    # input gradient only (no parameter gradients): same dx, gradient buffers untouched
+    before = [t.clone() for t in keep[0][3]]
+    d = descs[0]
+    d.gw1 = d.gb1 = d.gw2 = d.gb2 = d.gw3 = d.gb3 = None
+    keep[0][7].zero_()
+    L.check(lib.hhrl_mlp3_backward_group(descs, 1, M, st))
+    scaled_close("dx only", keep[0][7][:, :K0].cpu().numpy(), refs[0][1].numpy(), atol_rel=1e-5)
+    assert all(torch.equal(a, b) for a, b in zip(before, keep[0][3]))
