@@ -106,18 +106,24 @@ __device__ __forceinline__ void commit_w4(float* img, int ld, const float4 (&v)[
 //   A(i,k) = a[i*ASI + k*ASK]      B(k,j) = b[k*BSK + j*BSJ]
 // Result: column lane&15, rows 4*(lane>>4) + reg.  Two accumulation chains (even / odd groups of four k).
 template <int K, int ASI, int ASK, int BSK, int BSJ>
-__device__ __forceinline__ f32x4 wave_mma16(const float* a, const float* b, int lane, float init) {
+__device__ __forceinline__ f32x4 wave_mma16(const float* a, const float* b, int lane, f32x4 init) {
   static_assert(K % 8 == 0, "K must be a multiple of 8");
   const int i = lane & 15, q = lane >> 4;
   const float* ap = a + i * ASI + q * ASK;
   const float* bp = b + q * BSK + i * BSJ;
-  f32x4 c0 = {init, init, init, init}, c1 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 c0 = init, c1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < K; k += 8) {
     c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[k * ASK], bp[k * BSK], c0, 0, 0, 0);
     c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(k + 4) * ASK], bp[(k + 4) * BSK], c1, 0, 0, 0);
   }
   return c0 + c1;
+}
+// the same with one start value for the whole column (a bias)
+template <int K, int ASI, int ASK, int BSK, int BSJ>
+__device__ __forceinline__ f32x4 wave_mma16(const float* a, const float* b, int lane, float init) {
+  const f32x4 v = {init, init, init, init};
+  return wave_mma16<K, ASI, ASK, BSK, BSJ>(a, b, lane, v);
 }
 // img[(row0 + row)][col0 + col] = block
 template <int LD>

@@ -755,6 +755,251 @@ __global__ __launch_bounds__(256, 1) void vae_lane_forward_kernel(LaneArgs g) {
   }
 }
 
+// ------------------------------------------------------------------ inference: encode
+// DeepSetEncoder.forward alone (algorithm.py:40-47, Encoder.encode :109-116) for B lanes in one launch:
+// the forward chain above up to the heads.  Lanes may hold different numbers of cars (lane_start), a lane
+// without cars yields zeros like the reference's early return.
+struct EncArgs {
+  LaneArgs g;              // data = cars [total][2]; w, b, B, N, g, tiles
+  const int* lane_start;   // [B+1] first car of every lane, or null: N cars per lane
+  float* out;              // [B][ldo] mean | logvar
+  int ldo;
+};
+
+__global__ __launch_bounds__(256, 1) void vae_encode_kernel(EncArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const LaneArgs& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31;
+  const int rb = wave & 1, cb = wave >> 1, j16 = lane & 15, q16 = lane >> 4;
+  const int gd = g.g;
+  float* bs = lds + LW_BIAS;
+  float* Ih1 = lds + LI_H1;
+  float* Ipool = lds + LI_POOL;
+  float* Ir1 = lds + LI_R1;
+  float* Ir2 = lds + LI_R2;
+  float* Iml = lds + LI_ML;
+  float* cnt = lds + LI_TMP;           // cars per lane of the tile
+  {
+    RegsB rB;
+    RegsR rR;
+    float4 rho0[4];
+    request_bias(rB, g, tid);
+    request_w4<128, 32>(rho0, g.w[RHO0], tid);
+    const float4 phi2 = tid < 128 ? reinterpret_cast<const float4*>(g.w[PHI2])[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+    request_R(rR, g, tid);
+    commit_bias(lds, rB, tid);
+    commit_w4<128, 32>(lds + LW_RHO0, 33, rho0, tid);
+    if (tid < 128) commit4<16>(lds + LW_PHI2, 17, tid, phi2);
+    commit_R(lds, rR, g, tid);
+  }
+  __syncthreads();
+  for (int tile = blockIdx.x; tile < g.tiles; tile += gridDim.x) {
+    const int row0 = tile * 32;
+    // ---- phi.0 + ReLU summed over each lane's cars
+    for (int idx = tid; idx < 32 * 16; idx += 256) {
+      const int rr = idx >> 4, k = idx & 15;
+      const int b = row0 + rr;
+      float s = 0.f;
+      long c0 = 0, c1 = 0;
+      if (b < g.B) {
+        c0 = a.lane_start ? a.lane_start[b] : (long)b * g.N;
+        c1 = a.lane_start ? a.lane_start[b + 1] : c0 + g.N;
+        const float wa = g.w[PHI0][2 * k], wb = g.w[PHI0][2 * k + 1], bb = g.b[PHI0][k];
+        for (long c = c0; c < c1; ++c) s += fmaxf(wa * g.data[2 * c] + wb * g.data[2 * c + 1] + bb, 0.f);
+      }
+      Ih1[rr * 33 + k] = s;
+      if (k == 0) cnt[rr] = (float)(c1 - c0);
+    }
+    __syncthreads();
+    // ---- phi.2 on the summed hidden: pooled = W2 h1s + count * b2
+    {
+      const float b2 = bs[LB_PHI2 + 16 * cb + j16];
+      f32x4 init;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) init[e] = cnt[16 * rb + 4 * q16 + e] * b2;
+      const f32x4 c = wave_mma16<16, 33, 1, 1, 17>(Ih1 + 16 * rb * 33, lds + LW_PHI2 + 16 * cb * 17, lane, init);
+      store_block16<33>(Ipool, 16 * rb, 16 * cb, c, lane);
+    }
+    __syncthreads();
+    // ---- rho.0 (32 -> 128, ReLU)
+    {
+      f32x16 acc[1];
+      acc[0] = splat(bs[LB_RHO0 + wave * 32 + r]);
+      wave_mma<1, 32, 33, 1, 1, 33>(acc, Ipool, lds + LW_RHO0 + wave * 32 * 33, lane);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[0][i] = fmaxf(acc[0][i], 0.f);
+      store_tile<129>(Ir1, wave * 32, acc[0], lane);
+    }
+    __syncthreads();
+    // ---- rho.2 (128 -> 64)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int col0 = 32 * cb + 16 * t;
+      const f32x4 c = wave_mma16<128, 129, 1, 1, 129>(Ir1 + 16 * rb * 129, lds + LW_RHO2 + col0 * 129, lane,
+                                                      bs[LB_RHO2 + col0 + j16]);
+      store_block16<65>(Ir2, 16 * rb, col0, c, lane);
+    }
+    __syncthreads();
+    // ---- heads (64 -> 2g)
+    {
+      const f32x4 c = wave_mma16<64, 65, 1, 1, 65>(Ir2 + 16 * rb * 65, lds + LW_HEAD + 16 * cb * 65, lane,
+                                                   bs[LB_HEAD + 16 * cb + j16]);
+      store_block16<33>(Iml, 16 * rb, 16 * cb, c, lane);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = u * 256 + tid, rr = idx >> 5, c = idx & 31;
+      if (row0 + rr < g.B && c < 2 * gd) a.out[(long)(row0 + rr) * a.ldo + c] = cnt[rr] > 0.f ? Iml[rr * 33 + c] : 0.f;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ inference: decode
+// DeepSetDecoder.forward (algorithm.py:68-73) on rows (lane b, location n): z_b = mean + eps * exp(logvar / 2)
+// (Encoder.decode :121-127; eps == null: z = mean), decoder(z_b), loc embedding, func -> speed in (0, 1).
+struct DecArgs {
+  const float* w[NLAYER];
+  const float* b[NLAYER];
+  const float *goal, *eps, *loc;
+  float* out;
+  long rows;               // B * N
+  int ldg, ldl, ldo, N, g;
+};
+constexpr int DW_DEC0 = 0;                         // [128][17]
+constexpr int DW_DEC2 = DW_DEC0 + 128 * 17;        // [32][129]
+constexpr int DW_F0 = DW_DEC2 + 32 * 129;          // [128][65]
+constexpr int DW_F2 = DW_F0 + 128 * 65;            // [32][129]
+constexpr int DW_SMALL = DW_F2 + 32 * 129;         // bdec0[128] bdec2[32] bf0[128] bf2[32] w4[32] wloc[32] bloc[32] b4[1]
+constexpr int DI_Z = DW_SMALL + 420;               // [32][17]
+constexpr int DI_D1 = DI_Z + 32 * 17;              // [32][129]
+constexpr int DI_CAT = DI_D1 + 32 * 129;           // [32][65]
+constexpr int DI_F1 = DI_CAT + 32 * 65;            // [32][129]
+constexpr int DI_F2 = DI_F1 + 32 * 129;            // [32][33]
+constexpr int DEC_LDS_FLOATS = DI_F2 + 32 * 33;
+
+__global__ __launch_bounds__(256, 1) void vae_decode_kernel(DecArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31;
+  const int rb = wave & 1, cb = wave >> 1, j16 = lane & 15;
+  const int gd = g.g;
+  float* sm = lds + DW_SMALL;
+  float *bdec0 = sm, *bdec2 = sm + 128, *bf0 = sm + 160, *bf2 = sm + 288, *w4s = sm + 320, *wlocs = sm + 352, *blocs = sm + 384,
+        *b4s = sm + 416;
+  float* Iz = lds + DI_Z;
+  float* Id1 = lds + DI_D1;
+  float* Icat = lds + DI_CAT;
+  float* If1 = lds + DI_F1;
+  float* If2 = lds + DI_F2;
+  {
+    float4 f0[8], d2[4], f2[4];
+    float d0[8];
+    request_w4<128, 64>(f0, g.w[FUNC0], tid);
+    request_w4<32, 128>(d2, g.w[DEC2], tid);
+    request_w4<32, 128>(f2, g.w[FUNC2], tid);
+    const int nd = 128 * gd, lg = __ffs(gd) - 1;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = u * 256 + tid;
+      d0[u] = e < nd ? g.w[DEC0][e] : 0.f;
+    }
+    const float s0 = tid < 128 ? g.b[DEC0][tid] : g.b[FUNC0][tid - 128];
+    float s1 = 0.f;
+    if (tid < 32) s1 = g.b[DEC2][tid];
+    else if (tid < 64) s1 = g.b[FUNC2][tid - 32];
+    else if (tid < 96) s1 = g.w[FUNC4][tid - 64];
+    else if (tid < 128) s1 = g.w[LOC][tid - 96];
+    else if (tid < 160) s1 = g.b[LOC][tid - 128];
+    else if (tid == 160) s1 = g.b[FUNC4][0];
+    for (int i = tid; i < 128 * 17; i += 256)
+      if (i % 17 >= gd) lds[DW_DEC0 + i] = 0.f;
+    commit_w4<128, 64>(lds + DW_F0, 65, f0, tid);
+    commit_w4<32, 128>(lds + DW_DEC2, 129, d2, tid);
+    commit_w4<32, 128>(lds + DW_F2, 129, f2, tid);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = u * 256 + tid;
+      if (e < nd) lds[DW_DEC0 + (e >> lg) * 17 + (e & (gd - 1))] = d0[u];
+    }
+    if (tid < 128) bdec0[tid] = s0; else bf0[tid - 128] = s0;
+    if (tid < 32) bdec2[tid] = s1;
+    else if (tid < 64) bf2[tid - 32] = s1;
+    else if (tid < 96) w4s[tid - 64] = s1;
+    else if (tid < 128) wlocs[tid - 96] = s1;
+    else if (tid < 160) blocs[tid - 128] = s1;
+    else if (tid == 160) b4s[0] = s1;
+  }
+  __syncthreads();
+  for (long row0 = (long)blockIdx.x * 32; row0 < g.rows; row0 += (long)gridDim.x * 32) {
+    // ---- z of every row's lane, zero-padded to 16 columns
+    for (int idx = tid; idx < 32 * 16; idx += 256) {
+      const int rr = idx >> 4, j = idx & 15;
+      const long row = row0 + rr;
+      float zv = 0.f;
+      if (j < gd && row < g.rows) {
+        const long b = row / g.N;
+        const float mean = g.goal[b * g.ldg + j];
+        zv = g.eps ? mean + g.eps[b * gd + j] * expf(0.5f * g.goal[b * g.ldg + gd + j]) : mean;
+      }
+      Iz[rr * 17 + j] = zv;
+    }
+    __syncthreads();
+    // ---- decoder.0 (g -> 128, ReLU)
+    {
+      f32x16 acc[1];
+      acc[0] = splat(bdec0[wave * 32 + r]);
+      wave_mma<1, 16, 17, 1, 1, 17>(acc, Iz, lds + DW_DEC0 + wave * 32 * 17, lane);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[0][i] = fmaxf(acc[0][i], 0.f);
+      store_tile<129>(Id1, wave * 32, acc[0], lane);
+    }
+    __syncthreads();
+    // ---- decoder.2 (128 -> 32) into cat[:, 0:32]; loc embedding into cat[:, 32:64]
+    {
+      const f32x4 c = wave_mma16<128, 129, 1, 1, 129>(Id1 + 16 * rb * 129, lds + DW_DEC2 + 16 * cb * 129, lane, bdec2[16 * cb + j16]);
+      store_block16<65>(Icat, 16 * rb, 16 * cb, c, lane);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = u * 256 + tid, rr = idx >> 5, k = idx & 31;
+        const long row = row0 + rr;
+        const float loc = row < g.rows ? g.loc[(row / g.N) * g.ldl + (row % g.N)] : 0.f;
+        Icat[rr * 65 + 32 + k] = loc * wlocs[k] + blocs[k];
+      }
+    }
+    __syncthreads();
+    // ---- func.0 (64 -> 128, ReLU)
+    {
+      f32x16 acc[1];
+      acc[0] = splat(bf0[wave * 32 + r]);
+      wave_mma<1, 64, 65, 1, 1, 65>(acc, Icat, lds + DW_F0 + wave * 32 * 65, lane);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[0][i] = fmaxf(acc[0][i], 0.f);
+      store_tile<129>(If1, wave * 32, acc[0], lane);
+    }
+    __syncthreads();
+    // ---- func.2 (128 -> 32, ReLU)
+    {
+      f32x4 c = wave_mma16<128, 129, 1, 1, 129>(If1 + 16 * rb * 129, lds + DW_F2 + 16 * cb * 129, lane, bf2[16 * cb + j16]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) c[e] = fmaxf(c[e], 0.f);
+      store_block16<33>(If2, 16 * rb, 16 * cb, c, lane);
+    }
+    __syncthreads();
+    // ---- func.4 (32 -> 1) + sigmoid
+    if (tid < 32) {
+      const long row = row0 + tid;
+      if (row < g.rows) {
+        float s = b4s[0];
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) s += w4s[k] * If2[tid * 33 + k];
+        g.out[(row / g.N) * g.ldo + (row % g.N)] = 1.f / (1.f + expf(-s));
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------ backward
 // SINGLE: the grid covers every tile (one tile per workgroup, the case up to 8192 traffic lanes); a layer's
 // slab entries are then written right after the phase that completes them, under the later phases.
@@ -1283,6 +1528,76 @@ int hhrl_vae_learn_step(float* params, float* grads, float* m, float* v, const l
   HHRL_REQUIRE(step >= 1, "vae_learn_step: step=%d", step);
   const AdamK k = make_adam_k(lr, beta1, beta2, adam_eps, step, 1.0);
   return vae_step_impl(params, grads, m, v, &k, offsets, n_flat, data, eps, B, N, g, recon_scale, loss, ws, stream);
+}
+
+static int lane_layers(LaneArgs& la, const float* params, const long* offsets, long n_flat, int g, const char* who) {
+  static const long numel_w[NLAYER] = {32, 512, 4096, 8192, -64, -64, -128, 4096, 32, 8192, 4096, 32};
+  static const long numel_b[NLAYER] = {16, 32, 128, 64, -1, -1, 128, 32, 32, 128, 32, 1};
+  HHRL_REQUIRE(g == 2 || g == 4 || g == 8 || g == 16, "%s: latent size %d not in {2,4,8,16}", who, g);
+  for (int l = 0; l < NLAYER; ++l) {
+    const long ow = offsets[2 * l], ob = offsets[2 * l + 1];
+    const long nw = numel_w[l] < 0 ? -numel_w[l] * g : numel_w[l];
+    const long nb = numel_b[l] < 0 ? g : numel_b[l];
+    HHRL_REQUIRE(ow >= 0 && ow + nw <= n_flat && ob >= 0 && ob + nb <= n_flat, "%s: offsets[%d] outside the flat buffer", who, l);
+    HHRL_REQUIRE((ow & 3) == 0, "%s: weight %d is not 16-byte aligned inside the flat buffer", who, l);
+    la.w[l] = params + ow;
+    la.b[l] = params + ob;
+  }
+  return HHRL_OK;
+}
+
+int hhrl_vae_encode(const float* params, const long* offsets, long n_flat, const float* cars, const int* lane_start,
+                    int B, int N, int g, float* out, int ldo, void* stream) {
+  HHRL_REQUIRE(params && offsets && cars && out, "vae_encode: null pointer");
+  HHRL_REQUIRE(B > 0 && (lane_start != nullptr || N > 0) && ldo >= 2 * g, "vae_encode: bad shape B=%d N=%d ldo=%d", B, N, ldo);
+  EncArgs a;
+  HHRL_TRY(lane_layers(a.g, params, offsets, n_flat, g, "vae_encode"));
+  a.g.data = cars;
+  a.g.eps = nullptr; a.g.d2 = nullptr; a.g.act = nullptr; a.g.dpart = nullptr; a.g.slab = nullptr; a.g.kl_part = nullptr;
+  a.g.B = B; a.g.N = N; a.g.g = g; a.g.tiles = (B + 31) / 32;
+  a.lane_start = lane_start;
+  a.out = out;
+  a.ldo = ldo;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(vae_encode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            LN_LDS_FLOATS * 4) != hipSuccess)
+      return fail(HHRL_ERR_HIP, "vae_encode: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    attr_done = true;
+  }
+  hipStream_t st = as_stream(stream);
+  ProfScope ps("vae_encode_kernel", st, 0.0, 0.0);
+  hipLaunchKernelGGL(vae_encode_kernel, dim3(grid_lane(B)), dim3(256), LN_LDS_FLOATS * 4, st, a);
+  return launch_status("vae_encode_kernel");
+}
+
+int hhrl_vae_decode(const float* params, const long* offsets, long n_flat, const float* goal, int ldg, const float* eps,
+                    const float* loc, int ldl, int B, int N, int g, float* out, int ldo, void* stream) {
+  HHRL_REQUIRE(params && offsets && goal && loc && out, "vae_decode: null pointer");
+  HHRL_REQUIRE(B > 0 && N > 0 && ldg >= 2 * g && ldl >= N && ldo >= N, "vae_decode: bad shape B=%d N=%d ldg=%d ldl=%d ldo=%d", B, N, ldg,
+               ldl, ldo);
+  LaneArgs la;
+  HHRL_TRY(lane_layers(la, params, offsets, n_flat, g, "vae_decode"));
+  DecArgs a;
+  for (int l = 0; l < NLAYER; ++l) {
+    a.w[l] = la.w[l];
+    a.b[l] = la.b[l];
+  }
+  a.goal = goal; a.eps = eps; a.loc = loc; a.out = out;
+  a.rows = (long)B * N;
+  a.ldg = ldg; a.ldl = ldl; a.ldo = ldo; a.N = N; a.g = g;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(vae_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            DEC_LDS_FLOATS * 4) != hipSuccess)
+      return fail(HHRL_ERR_HIP, "vae_decode: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    attr_done = true;
+  }
+  const long tiles = (a.rows + 31) / 32;
+  hipStream_t st = as_stream(stream);
+  ProfScope ps("vae_decode_kernel", st, 0.0, 0.0);
+  hipLaunchKernelGGL(vae_decode_kernel, dim3((unsigned)(tiles < 1024 ? tiles : 1024)), dim3(256), DEC_LDS_FLOATS * 4, st, a);
+  return launch_status("vae_decode_kernel");
 }
 
 #ifdef HHRL_STAMPS

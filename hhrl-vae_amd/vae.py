@@ -7,7 +7,7 @@ torch is used for device memory and host<->device copies only.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -297,6 +297,18 @@ class Encoder:
         return float(loss.item()) if sync else loss
 
     # ------------------------------------------------------------ inference
+    def _encode_dev(self, cars: torch.Tensor, lane_start: Optional[torch.Tensor], B: int, N: int) -> torch.Tensor:
+        out = ops.dev_empty(B, 2 * self.goal_dim, device=self.device)
+        if self.fused:
+            check(self._lib.hhrl_vae_encode(self.params.base_ptr, self._offsets, self.layout.size, P(cars),
+                                            lane_start.data_ptr() if lane_start is not None else None, B, N,
+                                            self.goal_dim, P(out), 2 * self.goal_dim, _lib.stream_ptr()))
+            self._keep = (cars, lane_start)
+            return out
+        w = self._ws(B, N)
+        self._encode_fwd(cars, w)
+        return w.ml.clone()
+
     def encode(self, x) -> np.ndarray:
         """Encoder.encode (algorithm.py:109-116): one lane [N, 2] -> mean||logvar [2g]."""
         if len(x) == 0:
@@ -304,32 +316,64 @@ class Encoder:
         xt = self._to_device(x)
         if xt.dim() != 2 or xt.shape[1] != 2:
             raise ValueError("encode expects one lane [N, 2]")
-        w = self._ws(1, int(xt.shape[0]))
-        self._encode_fwd(xt, w)
-        return w.ml[0].cpu().numpy()
+        return self._encode_dev(xt, None, 1, int(xt.shape[0]))[0].cpu().numpy()
 
     def encode_batch(self, lanes: torch.Tensor) -> torch.Tensor:
         """[B, N, 2] lanes with a common car count -> [B, 2g] on the device."""
         xt = self._to_device(lanes)
-        w = self._ws(int(xt.shape[0]), int(xt.shape[1]))
-        self._encode_fwd(xt, w)
-        return w.ml.clone()
+        return self._encode_dev(xt, None, int(xt.shape[0]), int(xt.shape[1]))
+
+    def encode_lanes(self, lanes: Sequence) -> np.ndarray:
+        """Several lanes of different lengths (each [n_i, 2], possibly empty) in one launch -> [len(lanes), 2g]:
+        what agent.py:326, 748 build with one encode() call per lane."""
+        B = len(lanes)
+        if B == 0:
+            return np.zeros((0, 2 * self.goal_dim), dtype=np.float32)
+        counts = [len(l) for l in lanes]
+        if not self.fused or sum(counts) == 0:
+            return np.stack([np.asarray(self.encode(l), dtype=np.float32) for l in lanes])
+        cars = np.concatenate([np.asarray(l, dtype=np.float32).reshape(-1, 2) for l in lanes if len(l)], axis=0)
+        start = np.zeros(B + 1, dtype=np.int32)
+        np.cumsum(counts, out=start[1:])
+        out = self._encode_dev(torch.from_numpy(cars).to(self.device), torch.from_numpy(start).to(self.device), B, 0)
+        return out.cpu().numpy()
+
+    def decode_batch(self, goal, loc, eps=None) -> torch.Tensor:
+        """goal [B, 2g] (mean||logvar), loc [B, N] -> decoded speeds [B, N] on the device.  eps [B, g]:
+        reparameterisation noise (drawn on the device when omitted, algorithm.py:125)."""
+        g = self.goal_dim
+        goal_t = torch.as_tensor(goal, dtype=torch.float32).reshape(-1, 2 * g).to(self.device).contiguous()
+        B = int(goal_t.shape[0])
+        loc_t = torch.as_tensor(loc, dtype=torch.float32).reshape(B, -1).to(self.device).contiguous()
+        N = int(loc_t.shape[1])
+        if eps is None:
+            eps_t = torch.randn((B, g), generator=self._rng, device=self.device, dtype=torch.float32)
+        else:
+            eps_t = torch.as_tensor(eps, dtype=torch.float32).reshape(B, g).to(self.device).contiguous()
+        if self.fused:
+            out = ops.dev_empty(B, N, device=self.device)
+            check(self._lib.hhrl_vae_decode(self.params.base_ptr, self._offsets, self.layout.size, P(goal_t), 2 * g, P(eps_t),
+                                            P(loc_t), N, B, N, g, P(out), N, _lib.stream_ptr()))
+            self._keep = (goal_t, eps_t, loc_t)
+            return out
+        outs = []
+        for n in range(N):                       # per-layer path: one location column at a time
+            w = self._ws(B, 1)
+            w.ml.copy_(goal_t)
+            check(self._lib.hhrl_vae_reparam(P(w.ml), P(eps_t), P(w.z), B, g, _lib.stream_ptr()))
+            col = loc_t[:, n:n + 1].contiguous()
+            self._decode_fwd(P(col), 1, w)
+            outs.append(w.dec.clone())
+        return torch.cat(outs, dim=1)
 
     def decode(self, goal, loc, eps=None) -> np.ndarray:
         """Encoder.decode (algorithm.py:121-127): samples z from (mean, logvar)
         and decodes the speed at `loc`; shapes [2g] and [1] -> [1]."""
         g = self.goal_dim
-        goal_t = torch.as_tensor(np.asarray(goal, dtype=np.float32)).reshape(1, 2 * g).to(self.device)
-        loc_t = torch.as_tensor(np.asarray(loc, dtype=np.float32)).reshape(1, 1).to(self.device)
-        if eps is None:
-            eps_t = torch.randn((1, g), generator=self._rng, device=self.device, dtype=torch.float32)
-        else:
-            eps_t = torch.as_tensor(np.asarray(eps, dtype=np.float32)).reshape(1, g).to(self.device)
-        w = self._ws(1, 1)
-        w.ml.copy_(goal_t)
-        check(self._lib.hhrl_vae_reparam(P(w.ml), P(eps_t), P(w.z), 1, g, _lib.stream_ptr()))
-        self._decode_fwd(P(loc_t), 1, w)
-        return w.dec[0].cpu().numpy()
+        goal_np = np.asarray(goal, dtype=np.float32).reshape(1, 2 * g)
+        loc_np = np.asarray(loc, dtype=np.float32).reshape(1, 1)
+        eps_np = None if eps is None else np.asarray(eps, dtype=np.float32).reshape(1, g)
+        return self.decode_batch(goal_np, loc_np, eps_np)[0].cpu().numpy()
 
     # ------------------------------------------------------------ checkpoints
     def state_dict(self) -> Dict[str, torch.Tensor]:

@@ -154,6 +154,20 @@ int hhrl_vae_learn_step(float* params, float* grads, float* m, float* v, const l
                         double lr, double beta1, double beta2, double adam_eps, int step,
                         float* loss, float* ws, void* stream);
 
+/* Inference, one launch each.
+ * Encoder.encode / DeepSetEncoder.forward (algorithm.py:40-47, 109-116) for B lanes:
+ *   cars [total][2] (location, speed); lane_start [B+1] device ints = first car of every lane
+ *   (lanes of different lengths), or NULL for N cars per lane; out [B, 2g] (ld ldo) = mean | logvar.
+ *   A lane without cars gives zeros, as the reference's early return does.
+ * Encoder.decode / DeepSetDecoder.forward (algorithm.py:68-73, 121-127) for B lanes x N locations:
+ *   goal [B, 2g] (ld ldg) = mean | logvar; z = mean + eps*exp(logvar/2) with eps [B,g] from the
+ *   caller (NULL: z = mean); loc [B,N] (ld ldl); out [B,N] (ld ldo) = decoded speed in (0,1). */
+int hhrl_vae_encode(const float* params, const long* offsets, long n_flat, const float* cars,
+                    const int* lane_start, int B, int N, int g, float* out, int ldo, void* stream);
+int hhrl_vae_decode(const float* params, const long* offsets, long n_flat, const float* goal, int ldg,
+                    const float* eps, const float* loc, int ldl, int B, int N, int g,
+                    float* out, int ldo, void* stream);
+
 /* --------------------------------------------------------------------- TD3
  * Target-policy smoothing (algorithm.py:295-296, 494-497, 786-791, 1135-1136, 1330-1331):
  *   out = clamp(pi + clamp(0.2*eps, -0.5, 0.5), -1, 1);  eps ~ N(0,1) from the caller. */

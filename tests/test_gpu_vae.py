@@ -235,3 +235,41 @@ def test_vae_checkpoint_roundtrip(tmp_path):
         b = e2.learn(fx["step%d/x" % step], eps=fx["step%d/eps" % step])
         assert_close("loss", b, a, rtol=1e-6, atol=0)
     params_close("final", _np(e2.state_dict()), sub(fx, "final/param"), 3)
+
+
+@pytest.mark.parametrize("g", [2, 4, 8, 16])
+def test_vae_encode_decode_fused_vs_oracle(g):
+    """hhrl_vae_encode / hhrl_vae_decode (one launch each) against the CPU oracle: lanes of different
+    lengths incl. empty and 59-car lanes, uniform batches, batched decode over several locations."""
+    init = gen.gen_state(O.vae_param_shapes(g), 321 + g)
+    st = {k: torch.from_numpy(v) for k, v in init.items()}
+    e = _enc(g, init)
+    rs = np.random.RandomState(g)
+    counts = [7, 0, 1, 59, 16, 17, 3, 0, 33] + [int(c) for c in rs.randint(1, 40, size=60)]
+    lanes = [gen.gen_lanes(1, c, 100 + i)[0] if c else np.zeros((0, 2), dtype=np.float32) for i, c in enumerate(counts)]
+    got = e.encode_lanes(lanes)
+    assert got.shape == (len(lanes), 2 * g)
+    for i, lane in enumerate(lanes):
+        if len(lane) == 0:
+            assert not got[i].any()
+            continue
+        mean, logvar = O.deepset_encoder_forward(st, torch.from_numpy(lane))
+        scaled_close("encode_lanes[%d]" % i, got[i], torch.cat([mean, logvar], -1).numpy(), atol_rel=5e-6)
+        if i < 6:
+            scaled_close("encode[%d]" % i, e.encode(lane.tolist()), got[i], atol_rel=5e-6)
+    xb = gen.gen_lanes(300, 9, 5)
+    mean, logvar = O.deepset_encoder_forward(st, torch.from_numpy(xb))
+    scaled_close("encode_batch", e.encode_batch(torch.from_numpy(xb)).cpu().numpy(), torch.cat([mean, logvar], -1).numpy(), atol_rel=5e-6)
+    # decode: B lanes x N locations
+    B, N = 45, 5
+    goal = rs.standard_normal((B, 2 * g)).astype(np.float32) * 0.5
+    loc = rs.uniform(0, 1, size=(B, N)).astype(np.float32)
+    eps = rs.standard_normal((B, g)).astype(np.float32)
+    z = torch.from_numpy(goal[:, :g]) + torch.from_numpy(eps) * torch.exp(0.5 * torch.from_numpy(goal[:, g:]))
+    want = O.deepset_decoder_forward(st, z.unsqueeze(1).repeat(1, N, 1), torch.from_numpy(loc).unsqueeze(-1)).squeeze(-1)
+    scaled_close("decode_batch", e.decode_batch(goal, loc, eps).cpu().numpy(), want.numpy(), atol_rel=5e-6)
+    one = e.decode(goal[3], [loc[3, 2]], eps=eps[3])
+    scaled_close("decode", one, want[3, 2:3].numpy(), atol_rel=5e-6)
+    # the per-layer path gives the same numbers
+    el = _enc(g, init, fused=False)
+    scaled_close("decode_batch per-layer", el.decode_batch(goal, loc, eps).cpu().numpy(), want.numpy(), atol_rel=5e-6)
