@@ -103,6 +103,31 @@ def agent_update_rates(device, steps: int) -> dict:
     return out
 
 
+def inference_latency(enc, device) -> dict:
+    """Extra fields: the per-call inference surface the agents use every simulated second
+    (agent.py:326, 748, 809-811): one lane encoded per call as the reference does, eight lanes of one
+    intersection in one launch, one decode call.  Host round trip included (the callers need numpy)."""
+    rs = np.random.RandomState(7)
+    lanes = [synth_lanes(1, int(n), 50 + i)[0] for i, n in enumerate(rs.randint(1, 30, size=8))]
+    goal = rs.standard_normal(2 * enc.goal_dim).astype(np.float32) * 0.3
+    out = {}
+
+    def timed(fn, reps=200):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return 1e6 * (time.perf_counter() - t0) / reps
+    out["encode_one_lane_us"] = timed(lambda: enc.encode(lanes[0]))
+    out["encode_8_lanes_one_call_us"] = timed(lambda: enc.encode_lanes(lanes))
+    out["encode_8_lanes_8_calls_us"] = timed(lambda: [enc.encode(l) for l in lanes], reps=50)
+    out["decode_one_us"] = timed(lambda: enc.decode(goal, [0.4]))
+    return out
+
+
 def pmc_traffic(workload: str, kernel: str):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary
     of this workload (rocprofv3 FETCH_SIZE / WRITE_SIZE passes, read bytes
@@ -245,6 +270,7 @@ def main() -> None:
         }
         if world == 1 and not args.no_agents:
             out["agent_updates"] = agent_update_rates(device, max(20, min(args.steps, 100)))
+            out["inference"] = inference_latency(enc, device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_vae(B, N, g)
         print(json.dumps(out))
