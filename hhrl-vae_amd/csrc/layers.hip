@@ -27,13 +27,22 @@ __global__ __launch_bounds__(256) void act_grad_colsum_kernel(const float* __res
   const int r1 = min(M, r0 + rows_per_block);
   float s = 0.f;
   if (col < N) {
-    for (int r = r0 + ty; r < r1; r += rp) {
-      float gr = dy[(long)r * lddy + col];
-      if (act != HHRL_ACT_NONE) {
-        gr *= act_grad_from_output(y[(long)r * ldy + col], act);
-        dy[(long)r * lddy + col] = gr;
+    // rows_per_block = 16 * rp: every thread owns 16 rows, all of them requested before the first use
+    float gv[16], yv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int r = r0 + ty + u * rp;
+      gv[u] = r < r1 ? dy[(long)r * lddy + col] : 0.f;
+      yv[u] = (act != HHRL_ACT_NONE && r < r1) ? y[(long)r * ldy + col] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int r = r0 + ty + u * rp;
+      if (act != HHRL_ACT_NONE && r < r1) {
+        gv[u] *= act_grad_from_output(yv[u], act);
+        dy[(long)r * lddy + col] = gv[u];
       }
-      s += gr;
+      s += gv[u];
     }
   }
   if (db == nullptr) return;
@@ -61,13 +70,22 @@ __global__ __launch_bounds__(256) void act_grad_colsum_group_kernel(ActGradGroup
   if (blockIdx.x * cw >= g.N || r0 >= M) return;
   float s = 0.f;
   if (col < g.N) {
-    for (int r = r0 + ty; r < r1; r += rp) {
-      float gr = g.dy[(long)r * g.lddy + col];
-      if (g.act != HHRL_ACT_NONE) {
-        gr *= act_grad_from_output(g.y[(long)r * g.ldy + col], g.act);
-        g.dy[(long)r * g.lddy + col] = gr;
+    // rows_per_unit rows per thread (16), all of them requested before the first use
+    float gv[16], yv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int r = r0 + ty + u * rp;
+      gv[u] = (u < rows_per_unit && r < r1) ? g.dy[(long)r * g.lddy + col] : 0.f;
+      yv[u] = (g.act != HHRL_ACT_NONE && u < rows_per_unit && r < r1) ? g.y[(long)r * g.ldy + col] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int r = r0 + ty + u * rp;
+      if (g.act != HHRL_ACT_NONE && u < rows_per_unit && r < r1) {
+        gv[u] *= act_grad_from_output(yv[u], g.act);
+        g.dy[(long)r * g.lddy + col] = gv[u];
       }
-      s += gr;
+      s += gv[u];
     }
   }
   if (g.db == nullptr) return;

@@ -247,100 +247,90 @@ __global__ void lstm_cell_backward_kernel(CellBwdGroup grp, int B, int H) {
 // epilogue, the cell's backward for step t-1 on the same (row, unit) elements:
 //   dc_{t-1} = dc + dh_{t-1} * o * (1 - tanh(c_{t-1})^2), the four gate gradients of step t-1,
 //   and dc <- dc_{t-1} * f for the step before.
-// A workgroup owns 32 batch rows x 32 hidden units; its four waves each reduce one gate's H
-// columns of dgates_t (staged in LDS with the matching rows of W_hh), partial tiles are summed
-// in LDS in wave order.  Every (row, unit) element is owned by exactly one thread of the grid,
-// so dc is updated in place and dh never goes to memory.
+// A workgroup owns 16 batch rows x 16 hidden units (small tiles, many workgroups: the step is bound by
+// how fast one CU can pull its operands); its four waves each reduce one gate's H columns of dgates_t
+// on v_mfma_f32_16x16x4_f32, partial blocks are summed in LDS in wave order.  Every (row, unit) element
+// is owned by exactly one thread of the grid, so dc is updated in place and dh never goes to memory.
 struct StepBwdInst {
   const float *dgates_t, *w_hh, *gates_p, *c_pp, *c_p;   // gates_p: activated gates of step t-1; c_pp: cell before it (NULL = 0)
   float *dc, *dgates_p;
 };
 struct StepBwdGroup { StepBwdInst in[kMaxInst]; };
-static long step_bwd_lds_bytes(int H) { return 4L * (32L * (4 * H + 1) + 4L * H * 33 + 4 * 32 * 33); }
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+static int step_bwd_lda(int H) { return 4 * H + 4; }       // row stride of the dgates image: 4 mod 32 banks, 16-byte rows
+static long step_bwd_lds_bytes(int H) { return 4L * (16L * step_bwd_lda(H) + 4L * H * 17 + 4 * 16 * 17); }
 
 __global__ __launch_bounds__(256) void lstm_step_backward_kernel(StepBwdGroup grp, int B, int H) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const StepBwdInst& g = grp.in[blockIdx.z];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  const int u0 = blockIdx.x * 32, row0 = blockIdx.y * 32;
-  const int G4 = 4 * H, lda = G4 + 1;
-  float* Dg = lds;                        // [32][4H+1]  dgates_t rows
-  float* Wt = Dg + 32 * lda;              // [4H][33]    W_hh[k][u0 + j]
-  float* part = Wt + G4 * 33;             // [4][32][33]
+  const int u0 = blockIdx.x * 16, row0 = blockIdx.y * 16;
+  const int G4 = 4 * H, lda = G4 + 4;
+  float* Dg = lds;                        // [16][4H+4]  dgates_t rows
+  float* Wt = Dg + 16 * lda;              // [4H][17]    W_hh[k][u0 + j]
+  float* part = Wt + G4 * 17;             // [4][16][17]
   {
-    // 16-byte loads in batches of 8 per thread, all issued before their LDS writes
-    const int a4 = 32 * H;                // float4 count of the dgates tile (32 rows x 4H)
-    const int hq = H;                     // float4 per row = 4H/4
+    // 16-byte loads, 8 + 8 per thread for H = 128, all issued before the LDS writes
+    const int a4 = 16 * H;                // float4 count of the dgates tile (16 rows x 4H)
+    const int n4 = G4 * 4;                // W_hh[k][u0 .. u0+15]: 4 float4 per row k
     for (int base = 0; base < a4; base += 8 * 256) {
-      float4 v[8];
+      float4 v[8], wv[8];
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int i4 = base + it * 256 + tid;
-        const int rr = i4 / hq, c4 = i4 - rr * hq;
+        const int rr = i4 / H, c4 = i4 - rr * H;
         v[it] = (i4 < a4 && row0 + rr < B) ? reinterpret_cast<const float4*>(g.dgates_t + (long)(row0 + rr) * G4)[c4]
                                            : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int i4 = base + it * 256 + tid;
-        const int rr = i4 / hq, c4 = i4 - rr * hq;
-        if (i4 < a4) {
-          float* p = Dg + rr * lda + 4 * c4;
-          p[0] = v[it].x; p[1] = v[it].y; p[2] = v[it].z; p[3] = v[it].w;
-        }
-      }
-    }
-    const int n4 = G4 * 8;                // W_hh[k][u0 .. u0+31]: 8 float4 per row k
-    for (int base = 0; base < n4; base += 8 * 256) {
-      float4 wv[8];
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int i4 = base + it * 256 + tid;
-        const int k = i4 >> 3, c4 = i4 & 7;
-        wv[it] = (i4 < n4 && u0 + 4 * c4 + 3 < H) ? reinterpret_cast<const float4*>(g.w_hh + (long)k * H + u0)[c4]
+        const int k = i4 >> 2, w4 = i4 & 3;
+        wv[it] = (i4 < n4 && u0 + 4 * w4 + 3 < H) ? reinterpret_cast<const float4*>(g.w_hh + (long)k * H + u0)[w4]
                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int i4 = base + it * 256 + tid;
-        const int k = i4 >> 3, c4 = i4 & 7;
+        const int rr = i4 / H, c4 = i4 - rr * H;
+        if (i4 < a4) *reinterpret_cast<float4*>(Dg + rr * lda + 4 * c4) = v[it];
+        const int k = i4 >> 2, w4 = i4 & 3;
         if (i4 < n4) {
-          float* p = Wt + k * 33 + 4 * c4;
+          float* p = Wt + k * 17 + 4 * w4;
           p[0] = wv[it].x; p[1] = wv[it].y; p[2] = wv[it].z; p[3] = wv[it].w;
         }
       }
     }
   }
   __syncthreads();
-  f32x16 acc;
+  {
+    // wave `wave` reduces gate `wave`: k in [wave*H, (wave+1)*H), two accumulation chains
+    const int i = lane & 15, q = lane >> 4;
+    const float* ap = Dg + i * lda + wave * H + q;
+    const float* bp = Wt + (wave * H + q) * 17 + i;
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < H; k += 8) {
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[k], bp[k * 17], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[k + 4], bp[(k + 4) * 17], c1, 0, 0, 0);
+    }
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  const float* ap = Dg + r * lda + wave * H + h;
-  const float* bp = Wt + (wave * H + h) * 33 + r;
-  for (int k = 0; k < H; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k], bp[k * 33], acc, 0, 0, 0);
-#pragma unroll
-  for (int i = 0; i < 16; ++i) part[(wave * 32 + drow16(i, h)) * 33 + r] = acc[i];
+    for (int e = 0; e < 4; ++e) part[(wave * 16 + 4 * q + e) * 17 + i] = c0[e] + c1[e];
+  }
   __syncthreads();
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int idx = t * 256 + tid;
-    const int rr = idx >> 5, j = idx & 31;
+  {
+    const int rr = tid >> 4, j = tid & 15;
     const int b = row0 + rr, u = u0 + j;
-    if (b >= B || u >= H) continue;
-    const float dhv = (part[(0 * 32 + rr) * 33 + j] + part[(1 * 32 + rr) * 33 + j]) +
-                      (part[(2 * 32 + rr) * 33 + j] + part[(3 * 32 + rr) * 33 + j]);
-    const float* gr = g.gates_p + (long)b * G4;
-    const float gi = gr[u], gf = gr[H + u], gg = gr[2 * H + u], go = gr[3 * H + u];
-    const float tc = tanhf(g.c_p[(long)b * H + u]);
-    const float dcv = g.dc[(long)b * H + u] + dhv * go * (1.f - tc * tc);
-    const float cp = g.c_pp ? g.c_pp[(long)b * H + u] : 0.f;
-    float* dg = g.dgates_p + (long)b * G4;
-    dg[u] = dcv * gg * gi * (1.f - gi);
-    dg[H + u] = dcv * cp * gf * (1.f - gf);
-    dg[2 * H + u] = dcv * gi * (1.f - gg * gg);
-    dg[3 * H + u] = dhv * tc * go * (1.f - go);
-    g.dc[(long)b * H + u] = dcv * gf;
+    if (b < B && u < H) {
+      const float dhv = (part[(0 * 16 + rr) * 17 + j] + part[(1 * 16 + rr) * 17 + j]) +
+                        (part[(2 * 16 + rr) * 17 + j] + part[(3 * 16 + rr) * 17 + j]);
+      const float* gr = g.gates_p + (long)b * G4;
+      const float gi = gr[u], gf = gr[H + u], gg = gr[2 * H + u], go = gr[3 * H + u];
+      const float tc = tanhf(g.c_p[(long)b * H + u]);
+      const float dcv = g.dc[(long)b * H + u] + dhv * go * (1.f - tc * tc);
+      const float cp = g.c_pp ? g.c_pp[(long)b * H + u] : 0.f;
+      float* dg = g.dgates_p + (long)b * G4;
+      dg[u] = dcv * gg * gi * (1.f - gi);
+      dg[H + u] = dcv * cp * gf * (1.f - gf);
+      dg[2 * H + u] = dcv * gi * (1.f - gg * gg);
+      dg[3 * H + u] = dhv * tc * go * (1.f - go);
+      g.dc[(long)b * H + u] = dcv * gf;
+    }
   }
 }
 
@@ -355,8 +345,19 @@ __global__ __launch_bounds__(256) void colsum2_kernel(ColsumGroup grp, int ld, i
   const int r0 = blockIdx.y * rows_per_block, r1 = min(g.M, r0 + rows_per_block);
   if (r0 >= g.M) return;
   float s = 0.f;
-  if (col < N)
-    for (int r = r0 + ty; r < r1; r += 4) s += g.x[(long)r * ld + col];
+  if (col < N) {
+    // 16 rows per thread and pass, all requested before the first add (the loop is latency-bound otherwise)
+    for (int rb = r0 + ty; rb < r1; rb += 64) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int r = rb + 4 * u;
+        v[u] = r < r1 ? g.x[(long)r * ld + col] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += v[u];
+    }
+  }
   red[ty][tx] = s;
   __syncthreads();
   if (ty == 0 && col < N) {
@@ -540,9 +541,11 @@ int hhrl_lstm_backward_group(const hhrl_lstm_desc* d, int n, int B, int T, int H
     // all instances of a group share lddo only by convention: the column sums take it per launch
     for (int i = 1; i < n; ++i)
       HHRL_REQUIRE(d[i].lddo == d[0].lddo, "lstm_backward: instances of a group must share lddo (%d vs %d)", d[i].lddo, d[0].lddo);
-    ProfScope ps("colsum2_kernel", st, 0.0, 4.0 * B * H * n);
-    hipLaunchKernelGGL(colsum2_kernel, dim3(ceil_div(H, 64), ceil_div(B, 64), n), dim3(256), 0, st, cg, d[0].lddo, H, 64);
-    HHRL_TRY(launch_status("colsum2_kernel(fc)"));
+    {
+      ProfScope ps("colsum2_kernel", st, 0.0, 4.0 * B * H * n);
+      hipLaunchKernelGGL(colsum2_kernel, dim3(ceil_div(H, 64), ceil_div(B, 64), n), dim3(256), 0, st, cg, d[0].lddo, H, 64);
+      HHRL_TRY(launch_status("colsum2_kernel(fc)"));
+    }
     HHRL_TRY(gemm_group(dx, n, st));
     HHRL_TRY(gemm_group(dw, n, st));
   }
@@ -577,7 +580,7 @@ int hhrl_lstm_backward_group(const hhrl_lstm_desc* d, int n, int B, int T, int H
                              t > 1 ? w[i].cbuf + (long)(t - 1) * BH : nullptr, w[i].cbuf + (long)t * BH, w[i].dc,
                              w[i].dgates + (long)(t - 1) * B * G};
     ProfScope ps("lstm_step_backward_kernel", st, 2.0 * B * G * H * n, 4.0 * n * (B * (3.0 * G + 4.0 * H) + (double)G * H));
-    hipLaunchKernelGGL(lstm_step_backward_kernel, dim3(ceil_div(H, 32), ceil_div(B, 32), n), dim3(256), step_bwd_lds_bytes(H), st,
+    hipLaunchKernelGGL(lstm_step_backward_kernel, dim3(ceil_div(H, 16), ceil_div(B, 16), n), dim3(256), step_bwd_lds_bytes(H), st,
                        sg, B, H);
     HHRL_TRY(launch_status("lstm_step_backward_kernel"));
   }
