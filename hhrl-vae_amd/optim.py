@@ -3,6 +3,7 @@ optimizer `state_dict` format (the reference saves `optimizer.state_dict()`,
 algorithm.py:132, 333, 335 ...)."""
 from __future__ import annotations
 
+import math
 from typing import Dict
 
 import torch
@@ -40,10 +41,22 @@ class FlatAdam:
         _lib.check(self._lib.hhrl_adam_stage(self._hyper_dev.data_ptr(), self.lr, self.beta1, self.beta2, self.eps,
                                              self.step_count + 1, float(grad_scale), _lib.stream_ptr()))
 
-    def step_dev(self) -> None:
+    def next_step_scalars(self, grad_scale: float = 1.0):
+        """The eight kernel scalars of the NEXT step (count + 1, current lr) as the library computes them
+        (bias corrections in double): for callers that carry them to the device inside a transfer of
+        their own instead of through `stage_next_step`."""
+        t = self.step_count + 1
+        bc1 = 1.0 - math.pow(self.beta1, t)
+        bc2 = 1.0 - math.pow(self.beta2, t)
+        return (self.lr / bc1, self.beta1, self.beta2, 1.0 - self.beta1, 1.0 - self.beta2, math.sqrt(bc2), self.eps,
+                float(grad_scale))
+
+    def step_dev(self, hyper_ptr: int = 0) -> None:
+        """Adam step with the scalars read from device memory (`hyper_ptr`, eight floats; default: the
+        buffer filled by `stage_next_step`)."""
         _lib.check(self._lib.hhrl_adam_step_dev(
             self.p.base_ptr, self.g.base_ptr, self.m.base_ptr, self.v.base_ptr, self.p.layout.size,
-            self._hyper_dev.data_ptr(), _lib.stream_ptr()))
+            hyper_ptr or self._hyper_dev.data_ptr(), _lib.stream_ptr()))
 
     def commit_step(self) -> None:
         self.step_count += 1

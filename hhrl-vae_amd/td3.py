@@ -403,8 +403,7 @@ class TD3Learner:
         if group is not None:
             import torch.distributed as dist
             self.world_size = dist.get_world_size(group)
-        self._rng = torch.Generator(device=dev)
-        self._rng.manual_seed(3407)
+        self._np_rng = np.random.default_rng(3407 if seed is None else seed)     # smoothing noise (algorithm.py:295, 1330)
         self._loss = ops.dev_zeros(2, device=dev)
         self._statics: Dict[int, "TD3Learner._Static"] = {}
         self._graphs: Dict[tuple, "torch.cuda.CUDAGraph"] = {}
@@ -433,43 +432,63 @@ class TD3Learner:
     def _n_stored(self) -> int:
         raise NotImplementedError
 
-    def _upload(self, rows: np.ndarray) -> torch.Tensor:
-        return torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32))
-
     # ---- the update -------------------------------------------------------
     class _Static:
-        """Per-batch-size device buffers with fixed addresses (a captured graph replays on them)."""
+        """Per-batch-size device buffers with fixed addresses (a captured graph replays on them).
 
-        def __init__(self, fam: Family, B: int, dev):
-            self.rows = ops.dev_empty(B, fam.row_width, device=dev)
-            self.noise = [ops.dev_empty(B, a, device=dev) for a in fam.a_dims]
+        Everything an update needs from the host -- the sampled rows, the smoothing noise, the scalars of
+        the Adam steps -- sits in ONE device block that is refreshed by ONE transfer from a ring of pinned
+        host buffers (a slot is reused only after the transfer that read it has completed)."""
+
+        RING = 4
+
+        def __init__(self, fam: Family, B: int, dev, n_opt: int):
+            a64 = lambda n: (n + 63) & ~63
+            W = fam.row_width
+            self.n_rows = B * W
+            off = a64(self.n_rows)
+            self.noise_off = []
+            for a in fam.a_dims:
+                self.noise_off.append(off)
+                off += a64(B * a)
+            self.hyper_off = []
+            for _ in range(n_opt):
+                self.hyper_off.append(off)
+                off += 64
+            self.total = off
+            self.d_in = ops.dev_zeros(off, device=dev)
+            self.rows = self.d_in[:self.n_rows].view(B, W)
+            self.noise = [self.d_in[o:o + B * a].view(B, a) for o, a in zip(self.noise_off, fam.a_dims)]
+            self.hyper = [self.d_in[o:o + 8] for o in self.hyper_off]
+            self.h_in = [torch.zeros(off, dtype=torch.float32).pin_memory() for _ in range(self.RING)]
+            self.h_np = [t.numpy() for t in self.h_in]
+            self.events: List[Optional["torch.cuda.Event"]] = [None] * self.RING
+            self.turn = 0
             self.pi = [ops.dev_empty(B, a, device=dev) for a in fam.a_dims]
             self.y = ops.dev_empty(B, 1, device=dev)
 
-    def learn_rows(self, rows: torch.Tensor, noise: Optional[Sequence] = None, order: Optional[Sequence[int]] = None) -> None:
-        """One TD3 update on a [B, row_width] fp32 block of replay rows (host or device tensor).
+        def next_slot(self):
+            slot = self.turn % self.RING
+            self.turn += 1
+            if self.events[slot] is not None:
+                self.events[slot].synchronize()
+            return slot
+
+    def learn_rows(self, rows, noise: Optional[Sequence] = None, order: Optional[Sequence[int]] = None) -> None:
+        """One TD3 update on a [B, row_width] block of replay rows (numpy array, host or device tensor).
 
         The kernel sequence of an update depends only on (B, policy step?, actor order); after two
-        eager runs of a given combination it is captured into a HIP graph and replayed, with the
-        per-step scalars of Adam staged in device memory beforehand."""
+        eager runs of a given combination it is captured into a HIP graph and replayed.  What changes
+        from update to update (rows, noise, the scalars of the Adam steps) reaches the device in one
+        transfer before the replay."""
         fam = self.fam
         B, W = int(rows.shape[0]), fam.row_width
-        if rows.dim() != 2 or rows.shape[1] != W or B == 0:
+        if rows.ndim != 2 or rows.shape[1] != W or B == 0:
             raise ValueError("rows must be [B, %d], got %s" % (W, tuple(rows.shape)))
         st = self._statics.get(B)
         if st is None:
-            st = self._statics[B] = TD3Learner._Static(fam, B, self.device)
-        st.rows.copy_(rows)
+            st = self._statics[B] = TD3Learner._Static(fam, B, self.device, 1 + len(self.actors))
         n_act = len(self.actors)
-        if noise is None:
-            for e in st.noise:
-                e.normal_(generator=self._rng)
-        else:
-            for e, src, a in zip(st.noise, noise, fam.a_dims):
-                src = torch.as_tensor(np.asarray(src) if not isinstance(src, torch.Tensor) else src, dtype=torch.float32)
-                if tuple(src.shape) != (B, a):
-                    raise ValueError("noise must be [%d, %d], got %s" % (B, a, tuple(src.shape)))
-                e.copy_(src)
         self.total_it += 1
         policy = self.total_it % self.policy_freq == 0
         if policy:
@@ -480,11 +499,33 @@ class TD3Learner:
                 raise ValueError("order must be a permutation of range(%d)" % n_act)
         else:
             order = ()
-        # scalars of the Adam steps this update will take
-        self.critic.opt.stage_next_step()
+        # ---- one pinned block: rows | noise | scalars of the Adam steps this update will take
+        slot = st.next_slot()
+        h = st.h_np[slot]
+        rows_on_device = isinstance(rows, torch.Tensor) and rows.is_cuda
+        if not rows_on_device:
+            h[:st.n_rows].reshape(B, W)[:] = rows.numpy() if isinstance(rows, torch.Tensor) else rows
+        for k, (o, a) in enumerate(zip(st.noise_off, fam.a_dims)):
+            dst = h[o:o + B * a].reshape(B, a)
+            if noise is None:
+                dst[:] = self._np_rng.standard_normal((B, a), dtype=np.float32)
+            else:
+                src = noise[k].detach().cpu().numpy() if isinstance(noise[k], torch.Tensor) else np.asarray(noise[k])
+                if tuple(src.shape) != (B, a):
+                    raise ValueError("noise must be [%d, %d], got %s" % (B, a, tuple(src.shape)))
+                dst[:] = src
+        h[st.hyper_off[0]:st.hyper_off[0] + 8] = self.critic.opt.next_step_scalars()
         if policy:
-            for a in self.actors:
-                a.opt.stage_next_step()
+            for j, a in enumerate(self.actors):
+                h[st.hyper_off[1 + j]:st.hyper_off[1 + j] + 8] = a.opt.next_step_scalars()
+        if rows_on_device:
+            st.rows.copy_(rows)
+            st.d_in[st.n_rows:].copy_(st.h_in[slot][st.n_rows:], non_blocking=True)
+        else:
+            st.d_in.copy_(st.h_in[slot], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        st.events[slot] = ev
         key = (B, policy, order)
         graph = self._graphs.get(key)
         if graph is not None:
@@ -562,7 +603,7 @@ class TD3Learner:
         c.backward(B, both_heads=True, param_grads=True, lstms=False)
         self._lstm_backward([c.lstm_bwd_item(k, B) for k in range(n_str)], B)
         self._allreduce(c.opt.g)
-        c.opt.step_dev()
+        c.opt.step_dev(P(st.hyper[0]))
 
         # -- delayed policy step: :1353-1366 / 811-838
         if policy:
@@ -583,7 +624,7 @@ class TD3Learner:
                 if a.lstm is not None:
                     self._lstm_backward([a.lstm_bwd_item(B)], B)
                 self._allreduce(a.opt.g)
-                a.opt.step_dev()
+                a.opt.step_dev(P(st.hyper[1 + i]))
                 if n + 1 < len(order):                # later actors see this actor's new policy
                     a.forward(B, obs[i][0], W, goal, W, P(cw.xu, c.act_cols[i]), c.D, inputs_done=True)
             ops.polyak(self.critic_target.params, self.critic.params, fam.tau)
@@ -627,8 +668,7 @@ class TD3Learner:
     def _learn(self, indices=None, noise=None, order=None) -> None:
         if indices is None:
             indices = np.random.choice(min(self._n_stored(), self.memory_capacity), size=self.batch_size)
-        rows = self._upload(self._sample_rows(np.asarray(indices)))
-        self.learn_rows(rows, noise, order)
+        self.learn_rows(self._sample_rows(np.asarray(indices)), noise, order)
 
     # ---- inference --------------------------------------------------------
     def _act(self, k: int, obs, goal=None) -> np.ndarray:

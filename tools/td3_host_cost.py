@@ -18,16 +18,16 @@ for name, net, n in (("worker", WorkerTD3(gen.cav_cfg(cap=120000)), 120000), ("t
     t0 = time.perf_counter()
     for _ in range(K):
         idx = np.random.choice(n, size=net.batch_size)
-        rows = net._upload(net._sample_rows(idx))
+        rows = net._sample_rows(idx)
     gather = (time.perf_counter() - t0) / K
     st = net._statics[net.batch_size]
     t0 = time.perf_counter()
-    for _ in range(K): st.rows.copy_(rows)
+    for _ in range(K): st.d_in.copy_(st.h_in[0], non_blocking=True)
     torch.cuda.synchronize()
     h2d = (time.perf_counter() - t0) / K
-    rows_d = rows.cuda()
+    rows_d = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32)).cuda()
     t0 = time.perf_counter()
     for _ in range(K): net.learn_rows(rows_d)
     torch.cuda.synchronize()
     dev = (time.perf_counter() - t0) / K
-    print("%s: learn() %.1f us; host gather+convert %.1f us; H2D copy %.1f us; learn_rows(device rows) %.1f us" % (name, 1e6 * full, 1e6 * gather, 1e6 * h2d, 1e6 * dev))
+    print("%s: learn() %.1f us; host gather %.1f us; pinned H2D of rows+noise+scalars %.1f us; learn_rows(device rows) %.1f us" % (name, 1e6 * full, 1e6 * gather, 1e6 * h2d, 1e6 * dev))
