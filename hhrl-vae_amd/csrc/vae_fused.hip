@@ -101,11 +101,35 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
       in_d2[it] = b >= 0 ? g.d2[(long)b * 32 + r] : 0.f;
     }
   };
+  float* wl = lds + CAR_WAVE0 + wave * CAR_WAVE_FLOATS;
+  float* cat = wl + CAR_CAT;
+  float* half = wl + CAR_HALF;
+  float* f2i = wl + CAR_F2;
+  float* locs = wl + CAR_ROW;
+  float* vs = locs + 32;
+  float* dpre = vs + 32;
+  const float wl_r = g.wloc[r], bl_r = g.bloc[r];
+  // cat image of the fetched tile: [d2 of the car's lane | loc embedding], rows 2*it + h, column r
+  auto build_cat = [&]() {
+    if (h == 0) {
+      locs[r] = in_loc;
+      vs[r] = in_v;
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int rr = 2 * it + h;
+      const float loc_rr = __shfl(in_loc, rr, 64);
+      const int b_rr = __shfl(in_b, rr, 64);
+      cat[rr * 65 + r] = in_d2[it];
+      cat[rr * 65 + 32 + r] = b_rr >= 0 ? loc_rr * wl_r + bl_r : 0.f;
+    }
+  };
   fetch_tile(blockIdx.x * 4 + wave);
   {
     float4 v0[8], v2[4];
     request_w4<128, 64>(v0, g.w0, tid);
     request_w4<32, 128>(v2, g.w2, tid);
+    build_cat();                         // wave-private, under the weights' round trip
     commit_w4<128, 64>(W0s, 65, v0, tid);
     commit_w4<32, 128>(W2s, 129, v2, tid);
   }
@@ -120,14 +144,6 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
   __syncthreads();
   HHRL_STAMP(0, 1);
 
-  float* wl = lds + CAR_WAVE0 + wave * CAR_WAVE_FLOATS;
-  float* cat = wl + CAR_CAT;
-  float* half = wl + CAR_HALF;
-  float* f2i = wl + CAR_F2;
-  float* locs = wl + CAR_ROW;
-  float* vs = locs + 32;
-  float* dpre = vs + 32;
-
   // weight-gradient accumulators; the first tile starts its products from a zero operand instead of
   // zero-filling 192 registers that would then be live through its whole forward pass
   f32x16 dW0[4][2], dW2[4];
@@ -136,25 +152,12 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
 
   auto process_tile = [&](auto first_tag, int tile) {
     constexpr bool FIRST = decltype(first_tag)::value;
-    if (!FIRST) fetch_tile(tile);                                  // the first tile was requested in the prologue
-    const float loc = in_loc, v = in_v;
+    if (!FIRST) {                                                  // the first tile was prepared in the prologue
+      fetch_tile(tile);
+      build_cat();
+    }
+    const float v = in_v;
     const bool valid = in_b >= 0;
-    if (h == 0) {
-      locs[r] = loc;
-      vs[r] = v;
-    }
-    // cat image: [d2 of the car's lane | loc embedding], rows 2*it + h, column r
-    {
-      const float wl_r = wlocs[r], bl_r = blocs[r];
-#pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int rr = 2 * it + h;
-        const float loc_rr = __shfl(in_loc, rr, 64);
-        const int b_rr = __shfl(in_b, rr, 64);
-        cat[rr * 65 + r] = in_d2[it];
-        cat[rr * 65 + 32 + r] = b_rr >= 0 ? loc_rr * wl_r + bl_r : 0.f;
-      }
-    }
     wave_sync();
     HHRL_STAMP(0, 2);
 
@@ -338,70 +341,63 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
   b4acc = wave_sum(b4acc);
   lossacc = wave_sum(lossacc);
 
-  // ---- combine the four waves in LDS in a fixed order: waves 0 and 1 store into two buffers (the weight
-  //      images are dead by now), waves 2 and 3 add into them, the slab write adds the two buffers
+  // ---- combine the four waves in LDS in a fixed order.  Every image is dead by now: each wave stores
+  //      its tiles into a quarter of the LDS, all 256 threads then add the four quarters element-wise
+  //      ((w0 + w1) + (w2 + w3)) while writing the slab.  Two rounds: the func.0 gradient, then the rest.
   __syncthreads();
   HHRL_STAMP(0, 10);
-  constexpr int B_W0 = 0, B_B0 = 8192, B_W2 = B_B0 + 128, B_B2 = B_W2 + 4096, B_W4 = B_B2 + 32, B_B4 = B_W4 + 32;
-  constexpr int B_WLOC = B_B4 + 1, B_BLOC = B_WLOC + 32, B_LOSS = B_BLOC + 32, B_END = B_LOSS + 1;
-  static_assert(B_END <= CAR_WAVE0, "first combine buffer must fit in the weight region");
-  static_assert(B_END <= 4 * CAR_WAVE_FLOATS, "second combine buffer must fit in the wave regions");
-  float* bufA = lds;
-  float* bufB = lds + CAR_WAVE0;
-  for (int ph = 0; ph < 2; ++ph) {
-    if ((wave >> 1) == ph) {
-      float* buf = (wave & 1) ? bufB : bufA;
-      const bool first = ph == 0;
+  float* slab = g.slab + (long)blockIdx.x * g.off.total;
+  constexpr int Q0 = 8192;                           // floats per wave in round one: dW0 [128][64]
+  static_assert(4 * Q0 <= CAR_LDS_FLOATS, "combine buffers must fit the workgroup's LDS");
+  {
+    float* mine = lds + wave * Q0;
 #pragma unroll
-      for (int it = 0; it < 4; ++it)
+    for (int it = 0; it < 4; ++it)
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
+      for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            float* p = buf + B_W0 + (it * 32 + drow(i, h)) * 64 + jt * 32 + r;
-            *p = first ? dW0[it][jt][i] : *p + dW0[it][jt][i];
-          }
+        for (int i = 0; i < 16; ++i) mine[(it * 32 + drow(i, h)) * 64 + jt * 32 + r] = dW0[it][jt][i];
+  }
+  __syncthreads();
+  for (int i = tid; i < Q0; i += 256)
+    slab[g.off.w[FUNC0] + i] = (lds[i] + lds[Q0 + i]) + (lds[2 * Q0 + i] + lds[3 * Q0 + i]);
+  __syncthreads();
+  HHRL_STAMP(0, 11);
+  constexpr int B_W2 = 0, B_B0 = 4096, B_B2 = B_B0 + 128, B_W4 = B_B2 + 32, B_B4 = B_W4 + 32;
+  constexpr int B_WLOC = B_B4 + 1, B_BLOC = B_WLOC + 32, B_LOSS = B_BLOC + 32, Q1 = 4416;
+  static_assert(B_LOSS + 1 <= Q1 && 4 * Q1 <= CAR_LDS_FLOATS, "combine buffers must fit the workgroup's LDS");
+  {
+    float* mine = lds + wave * Q1;
 #pragma unroll
-      for (int jt = 0; jt < 4; ++jt)
+    for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          float* p = buf + B_W2 + drow(i, h) * 128 + jt * 32 + r;
-          *p = first ? dW2[jt][i] : *p + dW2[jt][i];
-        }
-      if (h == 0) {
+      for (int i = 0; i < 16; ++i) mine[B_W2 + drow(i, h) * 128 + jt * 32 + r] = dW2[jt][i];
+    if (h == 0) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          float* p = buf + B_B0 + t * 32 + r;
-          *p = first ? db0[t] : *p + db0[t];
-        }
-        float* p;
-        p = buf + B_B2 + r;   *p = first ? db2acc : *p + db2acc;
-        p = buf + B_W4 + r;   *p = first ? w4acc : *p + w4acc;
-        p = buf + B_WLOC + r; *p = first ? wlocacc : *p + wlocacc;
-        p = buf + B_BLOC + r; *p = first ? blocacc : *p + blocacc;
-        if (r == 0) {
-          p = buf + B_B4;   *p = first ? b4acc : *p + b4acc;
-          p = buf + B_LOSS; *p = first ? lossacc : *p + lossacc;
-        }
+      for (int t = 0; t < 4; ++t) mine[B_B0 + t * 32 + r] = db0[t];
+      mine[B_B2 + r] = db2acc;
+      mine[B_W4 + r] = w4acc;
+      mine[B_WLOC + r] = wlocacc;
+      mine[B_BLOC + r] = blocacc;
+      if (r == 0) {
+        mine[B_B4] = b4acc;
+        mine[B_LOSS] = lossacc;
       }
     }
-    __syncthreads();
   }
-  HHRL_STAMP(0, 11);
-  float* slab = g.slab + (long)blockIdx.x * g.off.total;
-  auto both = [&](int i) { return bufA[i] + bufB[i]; };
-  for (int i = tid; i < 8192; i += 256) slab[g.off.w[FUNC0] + i] = both(B_W0 + i);
-  for (int i = tid; i < 4096; i += 256) slab[g.off.w[FUNC2] + i] = both(B_W2 + i);
-  if (tid < 128) slab[g.off.b[FUNC0] + tid] = both(B_B0 + tid);
+  __syncthreads();
+  auto all4 = [&](int i) { return (lds[i] + lds[Q1 + i]) + (lds[2 * Q1 + i] + lds[3 * Q1 + i]); };
+  for (int i = tid; i < 4096; i += 256) slab[g.off.w[FUNC2] + i] = all4(B_W2 + i);
+  if (tid < 128) slab[g.off.b[FUNC0] + tid] = all4(B_B0 + tid);
   if (tid < 32) {
-    slab[g.off.b[FUNC2] + tid] = both(B_B2 + tid);
-    slab[g.off.w[FUNC4] + tid] = both(B_W4 + tid);
-    slab[g.off.w[LOC] + tid] = both(B_WLOC + tid);
-    slab[g.off.b[LOC] + tid] = both(B_BLOC + tid);
+    slab[g.off.b[FUNC2] + tid] = all4(B_B2 + tid);
+    slab[g.off.w[FUNC4] + tid] = all4(B_W4 + tid);
+    slab[g.off.w[LOC] + tid] = all4(B_WLOC + tid);
+    slab[g.off.b[LOC] + tid] = all4(B_BLOC + tid);
   }
   if (tid == 0) {
-    slab[g.off.b[FUNC4]] = both(B_B4);
-    g.loss_part[blockIdx.x] = both(B_LOSS);
+    slab[g.off.b[FUNC4]] = all4(B_B4);
+    g.loss_part[blockIdx.x] = all4(B_LOSS);
   }
   HHRL_STAMP(0, 12);
 }
