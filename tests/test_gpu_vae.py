@@ -1,5 +1,5 @@
 """VAE training path on the GPU (through the C ABI) against the golden vectors
-recorded from the reference and, at BASELINE sizes, against the CPU oracle on
+recorded from the reference and, at the benchmark sizes (4096 lanes), against the CPU oracle on
 the same inputs.  Bar: fp32, rtol 1e-4 (plus an absolute floor of 2e-6 of each
 tensor's largest magnitude, since fp32 sums in a different order cannot meet a
 pure rtol at values near zero)."""
@@ -117,7 +117,7 @@ def adam_conditioned_close(name, got_p, want_p, want_g, lr, g_floor, rtol=1e-4):
 
 @pytest.mark.parametrize("B,N,g", [(4096, 7, 4), (4096, 30, 4), (1000, 3, 16)])
 def test_vae_full_size_vs_oracle(B, N, g):
-    """BASELINE batch sizes: loss, every gradient, Adam moments and updated
+    """Benchmark batch sizes (4096 lanes x 7 and x 30 cars): loss, every gradient, Adam moments and updated
     parameters against the CPU oracle on identical inputs, for two consecutive
     steps (each step starts from the oracle's exact state)."""
     shapes = O.vae_param_shapes(g)
