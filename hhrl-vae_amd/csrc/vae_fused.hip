@@ -1318,16 +1318,17 @@ __global__ __launch_bounds__(256) void vae_reduce_grads_kernel(const float* __re
     // per-car layers (loc, func.*) occupy [car_lo, car_hi) and come from the per-car kernel's slabs
     const int n = (i >= car_lo && i < car_hi) ? n_car : n_lane;
     const float* col = slab + i;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    // eight independent running sums: eight slab rows in flight per thread
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
     int k = q;
-    for (; k + 12 < n; k += 16) {
-      s0 += col[(long)k * total];
-      s1 += col[(long)(k + 4) * total];
-      s2 += col[(long)(k + 8) * total];
-      s3 += col[(long)(k + 12) * total];
+    for (; k + 28 < n; k += 32) {
+      const float v0 = col[(long)k * total], v1 = col[(long)(k + 4) * total], v2 = col[(long)(k + 8) * total],
+                  v3 = col[(long)(k + 12) * total], v4 = col[(long)(k + 16) * total], v5 = col[(long)(k + 20) * total],
+                  v6 = col[(long)(k + 24) * total], v7 = col[(long)(k + 28) * total];
+      s0 += v0; s1 += v1; s2 += v2; s3 += v3; s4 += v4; s5 += v5; s6 += v6; s7 += v7;
     }
     for (; k < n; k += 4) s0 += col[(long)k * total];
-    s = (s0 + s1) + (s2 + s3);
+    s = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
   }
   red[q][p] = s;
   __syncthreads();
