@@ -636,6 +636,8 @@ __global__ __launch_bounds__(256, 1) void vae_lane_forward_kernel(LaneArgs g) {
   RegsP rP;
   RegsR rR;
   RegsD rD;
+  // phi.0 of hidden unit tid & 15 (every element this thread computes in the phi.0 phase uses that unit)
+  const float wa = g.w[PHI0][2 * (tid & 15)], wb = g.w[PHI0][2 * (tid & 15) + 1], bb = g.b[PHI0][tid & 15];
   request_bias(rB, g, tid);
   request_P(rP, g, blockIdx.x * 32, tid);
   request_R(rR, g, tid);
@@ -654,6 +656,13 @@ __global__ __launch_bounds__(256, 1) void vae_lane_forward_kernel(LaneArgs g) {
       commit_cars(lds, rP.cars, g, tid);
       __syncthreads();
     }
+    // the tile's reparameterisation noise, requested long before its phase: elements tid and tid + 256 of [32][16]
+    float eps_r[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = u * 256 + tid, rr = idx >> 4, j = idx & 15;
+      eps_r[u] = (j < gd && row0 + rr < g.B) ? g.eps[(long)(row0 + rr) * gd + j] : 0.f;
+    }
     HHRL_STAMP(1, 2);
     // ---- phi.0 + ReLU summed over each lane's cars
     for (int idx = tid; idx < 32 * 16; idx += 256) {
@@ -661,7 +670,6 @@ __global__ __launch_bounds__(256, 1) void vae_lane_forward_kernel(LaneArgs g) {
       const int b = row0 + rr;
       float s = 0.f;
       if (b < g.B) {
-        const float wa = g.w[PHI0][2 * k], wb = g.w[PHI0][2 * k + 1], bb = g.b[PHI0][k];
         const float* x = staged ? lds + LI_CARS + rr * g.N * 2 : g.data + (long)b * g.N * 2;
         for (int n = 0; n < g.N; ++n) s += fmaxf(wa * x[2 * n] + wb * x[2 * n + 1] + bb, 0.f);
       }
@@ -707,11 +715,11 @@ __global__ __launch_bounds__(256, 1) void vae_lane_forward_kernel(LaneArgs g) {
     __syncthreads();
     HHRL_STAMP(1, 7);
     // ---- reparameterisation z = mean + eps * exp(logvar / 2), zero-padded to 16 columns
-    for (int idx = tid; idx < 32 * 16; idx += 256) {
-      const int rr = idx >> 4, j = idx & 15;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = u * 256 + tid, rr = idx >> 4, j = idx & 15;
       float zv = 0.f;
-      if (j < gd && row0 + rr < g.B)
-        zv = Iml[rr * 33 + j] + g.eps[(long)(row0 + rr) * gd + j] * expf(0.5f * Iml[rr * 33 + gd + j]);
+      if (j < gd && row0 + rr < g.B) zv = Iml[rr * 33 + j] + eps_r[u] * expf(0.5f * Iml[rr * 33 + gd + j]);
       Iz[rr * 17 + j] = zv;
     }
     __syncthreads();
@@ -1018,6 +1026,8 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
   float* Itmp = lds + LI_TMP;   // dz, then t = dpooled * W_phi2
   const bool staged = g.N <= STAGE_MAX_CARS;
   HHRL_STAMP(2, 0);
+  // phi.0 of hidden unit tid & 15 (every element this thread handles in the phi.0 backward uses that unit)
+  const float wa = g.w[PHI0][2 * (tid & 15)], wb = g.w[PHI0][2 * (tid & 15) + 1], bb = g.b[PHI0][tid & 15];
 
   // weight-gradient tiles owned by this wave, kept across tiles
   f32x16 aDec2 = splat(0.f), aDec0 = splat(0.f), aHead = splat(0.f), aRho2a = splat(0.f), aRho2b = splat(0.f);
@@ -1090,6 +1100,13 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
     if (first) {
       request_bias(rB, g, tid);
       request_D(rD, g, tid);
+    }
+    // the noise of the tile's logvar columns, for the latent phase: elements tid + 256 u of [32][32]
+    float eps_r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = u * 256 + tid, rr = idx >> 5, c = idx & 31;
+      eps_r[u] = (c >= gd && c < 2 * gd && row0 + rr < g.B) ? g.eps[(long)(row0 + rr) * gd + c - gd] : 0.f;
     }
     // dd2 of a traffic lane = sum of the per-(lane, car tile) partial rows of the car tiles its cars span
     float dd2v[4];
@@ -1164,8 +1181,9 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
     __syncthreads();
     HHRL_STAMP(2, 3);
     // ---- latent gradient (KL + reparameterisation): dml = [dz + mean | dz*eps*0.5*std + 0.5*(exp(lv)-1) | 0...]
-    for (int idx = tid; idx < 32 * 32; idx += 256) {
-      const int rr = idx >> 5, c = idx & 31;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = u * 256 + tid, rr = idx >> 5, c = idx & 31;
       float outv = 0.f;
       if (c < 2 * gd && row0 + rr < g.B) {
         const int j = c < gd ? c : c - gd;
@@ -1175,7 +1193,7 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
           outv = dz + mean;
           klacc += -0.5f * (1.f + lv - mean * mean - expf(lv));
         } else {
-          outv = dz * g.eps[(long)(row0 + rr) * gd + j] * 0.5f * expf(0.5f * lv) + 0.5f * (expf(lv) - 1.f);
+          outv = dz * eps_r[u] * 0.5f * expf(0.5f * lv) + 0.5f * (expf(lv) - 1.f);
         }
       }
       Idml[rr * 33 + c] = outv;
@@ -1256,7 +1274,6 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
         const int b = row0 + rr;
         float a0 = 0.f, a1 = 0.f, c = 0.f;
         if (b < g.B) {
-          const float wa = g.w[PHI0][2 * k], wb = g.w[PHI0][2 * k + 1], bb = g.b[PHI0][k];
           const float* x = staged ? lds + LI_CARS + rr * g.N * 2 : g.data + (long)b * g.N * 2;
           for (int n = 0; n < g.N; ++n) {
             const float x0 = x[2 * n], x1 = x[2 * n + 1];
