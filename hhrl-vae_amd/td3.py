@@ -858,21 +858,19 @@ class HATD3Triple(_FlatReplayMixin, TD3Learner):
 
 
 class ManagerTD3(TD3Learner):
-    """algorithm.py:915-1184 (goal-only manager).  Off-policy correction
-    (`use_opc`, :1007-1107) is disabled in the reference's configuration
-    (configs.py:73) and is not provided here."""
+    """algorithm.py:915-1184 (goal-only manager), including the HIRO off-policy correction of the stored
+    goals (`use_opc`, :1007-1107, 1128-1132; switched off in the reference's configuration, configs.py:73)."""
 
     def __init__(self, cfg: dict, **kw):
-        if cfg["use_opc"]:
-            raise NotImplementedError("off-policy correction (use_opc=True) is outside the accelerated path")
         super().__init__(family_from_cfg("manager", cfg), **kw)
-        self.use_opc = False
+        self.use_opc = bool(cfg["use_opc"])
         s = self.fam.streams[0]
         self.o_dim, self.a_dim, self.s_dim, self.t = s.o, self.fam.a_dims[0], s.s, s.T
         self.obs_dim = s.width
         self.choose_goal = self.choose_action
         self.memory = DictReplay(self.memory_capacity, self.obs_dim, self.a_dim, 25, self.use_opc)
         self.store_transition = self.memory.store_transition
+        self._worker_policy = None
 
     @property
     def pointer(self):
@@ -883,13 +881,65 @@ class ManagerTD3(TD3Learner):
 
     def _sample_rows(self, indices):
         m = self.memory
-        return np.hstack((m["obs"][indices], m["action"][indices], m["reward"][indices], m["next_obs"][indices]))
+        action = m["action"][indices]
+        if self.use_opc:
+            if self._worker_policy is None:
+                raise ValueError("use_opc=True: learn() needs the worker policy (algorithm.py:1109, 1130)")
+            action = self.off_policy_corrections(self._worker_policy, action, m["worker_obs"][indices], m["worker_act"][indices])
+        return np.hstack((m["obs"][indices], action, m["reward"][indices], m["next_obs"][indices]))
+
+    @staticmethod
+    def off_policy_corrections(worker_policy, sgoals, wstates, wactions, candidate_goals: int = 8) -> np.ndarray:
+        """Re-labels the stored manager goals (algorithm.py:1007-1107): per lane, among the stored goal,
+        the observed change of the goal feature and `candidate_goals` samples around it, the candidate
+        under which the current worker policy best reproduces the stored worker actions.
+
+        sgoals [B, L]; wstates [B, S, L, wo]; wactions [B, S, L, wa] -> corrected goals [B, L].
+        The random candidates are drawn lane by lane from numpy's global generator, in the reference's
+        order; the policy is then evaluated for every (lane, candidate, row, step) in ONE batched call
+        instead of L * (candidate_goals + 2) calls."""
+        st = np.transpose(np.asarray(wstates), (2, 0, 1, 3))             # [L, B, S, wo]
+        act = np.transpose(np.asarray(wactions), (2, 0, 1, 3))           # [L, B, S, wa]
+        goals = np.transpose(np.asarray(sgoals), (1, 0))                 # [L, B]
+        L, B, S, wo = st.shape
+        wa = act.shape[-1]
+        gdim = 1                                                         # one goal value per lane (:1036)
+        C = candidate_goals + 2
+        cands = np.empty((L, B, C, gdim))
+        for lane in range(L):
+            diff = (st[lane][:, -1] - st[lane][:, 0])[:, None, -gdim:]                    # [B, 1, gdim]
+            orig = goals[lane][:, None, None]
+            rnd = np.random.normal(loc=diff, scale=.5, size=(B, candidate_goals, gdim)).clip(-1, 1)
+            cands[lane] = np.concatenate([orig, diff, rnd], axis=1)
+        # goal seen by the worker at step s under candidate c: (c + state_0) - state_s on the goal feature (:1073)
+        start = st[:, :, 0, -gdim:]                                       # [L, B, gdim]
+        cand_t = np.transpose(cands, (0, 2, 1, 3))                        # [L, C, B, gdim]
+        goal_in = (cand_t + start[:, None])[:, :, :, None, :] - st[:, None, :, :, -gdim:]     # [L, C, B, S, gdim]
+        obs_in = np.broadcast_to(st[:, None], (L, C, B, S, wo))
+        flat_obs = np.ascontiguousarray(obs_in).reshape(-1, wo)
+        pa = np.asarray(worker_policy(flat_obs, goal_in.reshape(-1, gdim)), dtype=np.float64).reshape(L, C, B, S, wa)
+        # Steps without a controlled vehicle take action -1 instead of the policy's (:1084-1086).  The
+        # reference tests `np.any` of the masked row NUMBERS of a lane, so a lane whose only masked
+        # step is row 0 keeps the policy's action there; kept as is.
+        mask = st[..., 0] == -1                                           # [L, B, S]
+        mask &= mask.reshape(L, -1)[:, 1:].any(axis=1)[:, None, None]
+        pa[np.broadcast_to(mask[:, None], (L, C, B, S))] = -1
+        diff = pa - act[:, None]
+        diff = np.where(diff != -np.inf, diff, 0)
+        logprob = -0.5 * np.sum(np.linalg.norm(diff, axis=-1) ** 2, axis=-1)                 # [L, C, B]
+        best = np.argmax(logprob, axis=1)                                 # [L, B]
+        res = np.take_along_axis(cands, best[:, :, None, None], axis=2)[:, :, 0, 0]          # [L, B]
+        return np.transpose(res, (1, 0))
 
     def choose_action(self, o_l):
         return self._act(0, o_l).flatten()
 
     def learn(self, worker_policy=None, indices=None, noise=None, order=None):
-        self._learn(indices, noise, order)
+        self._worker_policy = worker_policy
+        try:
+            self._learn(indices, noise, order)
+        finally:
+            self._worker_policy = None
 
 
 class WorkerTD3(_FlatReplayMixin, TD3Learner):

@@ -451,7 +451,8 @@ class TD3:
     """Functional twin of the reference's TD3 variants.
 
     ``learn(batch, noise, order)`` follows WorkerTD3.learn (algorithm.py:1316-1366),
-    TD3Single.learn (:283-328), ManagerTD3.learn (:1109-1168, use_opc=False),
+    TD3Single.learn (:283-328), ManagerTD3.learn (:1109-1168; with use_opc the caller relabels the
+    batch's actions with `off_policy_corrections` first),
     HATD3Double.learn (:479-542) and HATD3Triple.learn (:768-838).
     """
 
@@ -537,3 +538,48 @@ class TD3:
         g = None if goal is None else torch.as_tensor(np.asarray(goal, dtype=np.float32)).reshape(1, -1)
         o2 = o if s.T > 1 else o.reshape(1, -1)
         return actor_forward(self.actors[k], self.fam, k, o2, g).numpy().flatten()
+
+    @torch.no_grad()
+    def policy(self, obs, goal) -> np.ndarray:
+        """WorkerTD3.policy (algorithm.py:1310-1314): actor 0 on n rows of (observation, goal)."""
+        o = torch.as_tensor(np.asarray(obs, dtype=np.float32))
+        g = torch.as_tensor(np.asarray(goal, dtype=np.float32))
+        return actor_forward(self.actors[0], self.fam, 0, o, g).numpy()
+
+
+def off_policy_corrections(worker_policy, sgoals, wstates, wactions, candidate_goals: int = 8) -> np.ndarray:
+    """ManagerTD3.off_policy_corrections (algorithm.py:1007-1107), one lane and one candidate at a time.
+
+    sgoals [B, L] stored manager goals; wstates [B, S, L, wo] / wactions [B, S, L, wa] what the workers
+    saw and did while that goal was active.  Per lane the candidates are the stored goal, the change of
+    the goal feature (last observation feature) over the S steps, and `candidate_goals` normal draws
+    around that change (sigma 0.5, clipped to [-1, 1], numpy's global generator).  The goal a worker
+    sees at step s under candidate c is c + feature_0 - feature_s (:1073).  Steps whose first
+    observation feature is -1 take action -1 (:1084-1086; `np.any` is applied to the row NUMBERS there,
+    so a lane whose only such row is row 0 is left alone -- reproduced).  Score = -0.5 * sum over steps
+    of the squared action error (:1096); the best-scoring candidate replaces the stored goal.
+    """
+    wstates, wactions, sgoals = np.asarray(wstates), np.asarray(wactions), np.asarray(sgoals)
+    B, S, L, wo = wstates.shape
+    wa = wactions.shape[-1]
+    out = np.zeros((B, L))
+    for lane in range(L):
+        st = wstates[:, :, lane, :]                                   # [B, S, wo]
+        ac = wactions[:, :, lane, :].reshape(B * S, wa)
+        feat = st[:, :, -1:]                                          # the goal feature, [B, S, 1]
+        change = (st[:, -1] - st[:, 0])[:, None, -1:]                 # [B, 1, 1]
+        draws = np.random.normal(loc=change, scale=.5, size=(B, candidate_goals, 1)).clip(-1, 1)
+        cands = np.concatenate([sgoals[:, lane][:, None, None], change, draws], axis=1)      # [B, C, 1]
+        rows = st.reshape(B * S, wo)
+        empty = np.where(rows[:, 0] == -1)
+        score = np.zeros((B, cands.shape[1]))
+        for c in range(cands.shape[1]):
+            seen = (cands[:, c] + feat[:, 0])[:, None] - feat         # [B, S, 1]
+            a = np.array(worker_policy(rows, seen.reshape(B * S, 1)), dtype=np.float64)
+            if np.any(empty):
+                a[empty] = -1
+            err = a - ac
+            err = np.where(err != -np.inf, err, 0).reshape(B, S, wa)
+            score[:, c] = -0.5 * np.sum(np.linalg.norm(err, axis=-1) ** 2, axis=-1)
+        out[:, lane] = cands[np.arange(B), np.argmax(score, axis=-1), 0]
+    return out

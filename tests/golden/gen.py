@@ -104,5 +104,14 @@ TD3_CASES = {
 }
 
 
+def opc_cfgs() -> Tuple[dict, dict]:
+    """Manager (use_opc=True, one goal per lane: 8) and worker (8 features, 1 goal value, no LSTM)
+    configs of the off-policy-correction fixture td3_manager_opc.npz."""
+    m = light_cfg(o=(5, 5, 7), T=4, s=8, a=(1, 2, 8), actor_h=(12, 10), critic_h=(14, 12), veh_h=(12, 10),
+                  batch=8, cap=48, a_sched=1, c_sched=2)
+    m["use_opc"] = True
+    return m, cav_cfg(o=8, g=1, hidden=(16, 12), batch=8, cap=48)
+
+
 def case_seed(case: str, what: str) -> int:
     return _seed(case, what)

@@ -131,8 +131,55 @@ def test_td3_store_and_sample_surface():
         m.store_transition(rs.rand(28), rs.rand(3), 0.25, rs.rand(28), None, None)
     assert m.pointer == 10 and m.memory["reward"][3, 0] == 0.25
     m.learn(None); m.learn(None)
-    with pytest.raises(NotImplementedError):
-        A.ManagerTD3(dict(gen.light_cfg(), use_opc=True))
+    mcfg, wcfg = gen.opc_cfgs()
+    mo, wk = A.ManagerTD3(dict(mcfg, memory_capacity=16)), A.WorkerTD3(wcfg)
+    for i in range(10):
+        mo.store_transition(rs.rand(28), rs.rand(8), 0.25, rs.rand(28), rs.rand(25, 8, 8), rs.rand(25, 8, 1))
+    assert mo.memory["worker_obs"].shape == (16, 25, 8, 8) and mo.memory["worker_act"][9].any() and not mo.memory["worker_act"][10].any()
+    with pytest.raises(ValueError):
+        mo.learn(None)                                     # relabelling needs the worker's policy
+    mo.learn(wk.policy); mo.learn(wk.policy)
+    assert mo.total_it == 2
+
+
+def test_td3_manager_off_policy_correction():
+    """ManagerTD3.learn(worker.policy) with use_opc=True against the reference (tests/golden/make_opc.py):
+    numpy's global generator seeded as in the recording, so `learn` draws the same indices and the same
+    candidate goals; the worker policy runs on the GPU in one batched call.  The relabelled goals must
+    be the reference's exactly: they are candidates picked by an argmax, and the recording seeds were
+    chosen so that every decision wins by >= 1e-4 in score (`margin` in the fixture) where fp32
+    differences between policy implementations move scores by ~1e-6.  The update that follows is
+    held to the usual fp32 bar."""
+    import hhrl_vae_amd.algorithm as A
+    fx = load_case("td3_manager_opc")
+    mcfg, wcfg = gen.opc_cfgs()
+    net, worker = A.ManagerTD3(mcfg), A.WorkerTD3(wcfg)
+    net.load_state_dicts({"actor": sub(fx, "learn/init/actor"), "critic": sub(fx, "learn/init/critic")})
+    worker.load_state_dicts({"actor": sub(fx, "learn/init/worker_actor")})
+    rows = fx["learn/rows"]
+    fill_memory(net, "manager", rows)
+    n = rows.shape[0]
+    net.memory["worker_obs"][:n], net.memory["worker_act"][:n] = fx["learn/worker_obs"], fx["learn/worker_act"]
+    seen = []
+    real = net.off_policy_corrections
+    net.off_policy_corrections = lambda *a, **kw: seen.append(real(*a, **kw)) or seen[-1]
+    for call in range(int(fx["learn/n_calls"])):
+        pre = "learn/call%d" % call
+        assert fx[pre + "/margin"].min() >= 1e-4
+        np.random.seed(int(fx[pre + "/seed"]))
+        net.learn(worker.policy, noise=[fx[pre + "/eps0"]])
+        assert np.array_equal(seen[-1], fx[pre + "/corrected"]), pre
+        scaled_close(pre + "/mse", net.last_critic_loss.cpu().numpy(), fx[pre + "/mse"])
+        close_dict(pre + "/grad/critic", net.critic.opt.g.state_dict(), sub(fx, pre + "/grad/critic"), False, atol_rel=5e-6)
+        close_dict(pre + "/param/critic", net.critic.params.state_dict(), sub(fx, pre + "/param/critic"), False)
+        if bool(fx[pre + "/policy"]):
+            close_dict(pre + "/grad/actor", net.actors[0].opt.g.state_dict(), sub(fx, pre + "/grad/actor"), False, atol_rel=5e-6)
+            close_dict(pre + "/param/actor", net.actors[0].params.state_dict(), sub(fx, pre + "/param/actor"), False)
+            close_dict(pre + "/target/actor", net.actor_targets[0].params.state_dict(), sub(fx, pre + "/target/actor"), False)
+            close_dict(pre + "/target/critic", net.critic_target.params.state_dict(), sub(fx, pre + "/target/critic"), False)
+    assert len(seen) == 4
+    close_dict("exp_avg/critic", net.critic.opt.m.state_dict(), sub(fx, "learn/final/exp_avg/critic"), False, atol_rel=5e-6)
+    close_dict("exp_avg_sq/critic", net.critic.opt.v.state_dict(), sub(fx, "learn/final/exp_avg_sq/critic"), False, atol_rel=1e-5)
 
 
 def test_td3_checkpoint_roundtrip(tmp_path):

@@ -97,3 +97,32 @@ def test_shard_bounds_cover_batch_once():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _closed_form_policy(w, c):
+    return lambda o, g: np.tanh((np.asarray(o, dtype=np.float64) * w).sum(axis=1, keepdims=True) + np.asarray(g, dtype=np.float64) * c)
+
+
+@pytest.mark.parametrize("impl", ["oracle", "product"])
+def test_off_policy_correction_matches_reference(impl):
+    """ManagerTD3.off_policy_corrections against the reference's output (tests/golden/make_opc.py)
+    with a closed-form worker policy: same global numpy seed, bit-equal corrected goals.  Covers lanes
+    with no controlled vehicle and the lane whose only marked row is row 0."""
+    fx = load_case("td3_manager_opc")
+    if impl == "oracle":
+        fn = O.off_policy_corrections
+    else:
+        from hhrl_vae_amd.td3 import ManagerTD3
+        fn = ManagerTD3.off_policy_corrections
+    calls = []
+
+    def policy(o, g):
+        calls.append(len(o))
+        return _closed_form_policy(fx["fn/w"], float(fx["fn/c"]))(o, g)
+    np.random.seed(int(fx["fn/seed"]))
+    got = fn(policy, fx["fn/goals"], fx["fn/worker_obs"], fx["fn/worker_act"])
+    assert got.shape == fx["fn/corrected"].shape == (6, 8)
+    assert np.array_equal(got, fx["fn/corrected"])
+    assert np.array_equal(got[:, 2], fx["fn/goals"][:, 2].astype(np.float64))       # all candidates tie -> stored goal kept
+    if impl == "product":
+        assert calls == [8 * 10 * 6 * 25]                        # every lane and candidate in one policy call

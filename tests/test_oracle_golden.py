@@ -124,3 +124,34 @@ def test_td3_case(case):
                 got = O.actor_forward(net.actors[0], fam, 0, torch.from_numpy(fx["policy/o"].astype(np.float32)),
                                       torch.from_numpy(fx["policy/g"].astype(np.float32))).numpy()
             assert_close("policy", got, fx["policy/out"], **TOL)
+
+
+def test_td3_manager_off_policy_correction():
+    """Manager updates with use_opc=True (tests/golden/make_opc.py): the oracle's relabelling with the
+    oracle's worker policy picks the reference's goals exactly, and the update that follows matches."""
+    fx = load_case("td3_manager_opc")
+    mcfg, wcfg = gen.opc_cfgs()
+    fam, wfam = O.family_from_cfg("manager", mcfg), O.family_from_cfg("worker", wcfg)
+    worker = O.TD3(wfam, [_t(sub(fx, "learn/init/worker_actor"))],
+                   {k: torch.zeros(s) for k, s in O.critic_param_shapes(wfam)})
+    net = O.TD3(fam, [_t(sub(fx, "learn/init/actor"))], _t(sub(fx, "learn/init/critic")))
+    rows, wobs, wact = fx["learn/rows"], fx["learn/worker_obs"], fx["learn/worker_act"]
+    od, ad = fam.streams[0].width, fam.a_dims[0]
+    npd = lambda d: {k: v.detach().numpy() for k, v in d.items()}
+    for call in range(int(fx["learn/n_calls"])):
+        pre = "learn/call%d" % call
+        np.random.seed(int(fx[pre + "/seed"]))
+        idx = np.random.choice(rows.shape[0], size=mcfg["batch_size"])
+        assert np.array_equal(idx, fx[pre + "/indices"])
+        batch = rows[idx].astype(np.float32)
+        goals = O.off_policy_corrections(worker.policy, batch[:, od: od + ad], wobs[idx], wact[idx])
+        assert np.array_equal(goals, fx[pre + "/corrected"])
+        batch[:, od: od + ad] = goals
+        out = net.learn(O.split_rows(fam, batch), [torch.from_numpy(fx[pre + "/eps0"])])
+        assert_close(pre + "/critic_loss", out["critic_loss"], fx[pre + "/mse"].sum(), **TOL)
+        assert_dict_close(pre + "/grad/critic", npd(out["critic_grads"]), sub(fx, pre + "/grad/critic"), **TOL)
+        assert_dict_close(pre + "/param/critic", npd(net.critic), sub(fx, pre + "/param/critic"), **TOL)
+        if bool(fx[pre + "/policy"]):
+            assert_dict_close(pre + "/grad/actor", npd(out["actor_grads"][0]), sub(fx, pre + "/grad/actor"), **TOL)
+            assert_dict_close(pre + "/param/actor", npd(net.actors[0]), sub(fx, pre + "/param/actor"), **TOL)
+            assert_dict_close(pre + "/target/critic", npd(net.critic_target), sub(fx, pre + "/target/critic"), **TOL)
