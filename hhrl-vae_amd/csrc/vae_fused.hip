@@ -89,16 +89,22 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
   float in_loc, in_v, in_d2[16];
   int in_b;
   auto fetch_tile = [&](int tile) {
-    const long row = (long)tile * 32 + r;
+    const int row = tile * 32 + r;                                   // the host keeps the car count below 2^31
     const bool valid = tile < g.tiles && row < g.rows;
-    in_loc = valid ? g.data[row * 2] : 0.f;
-    in_v = valid ? g.data[row * 2 + 1] : 0.f;
-    in_b = valid ? (int)(row / g.N) : -1;
-    // rows 2*it + h of the d2 block: lane r reads column r of the traffic lane of car 2*it + h
+    const float2 lv = valid ? *reinterpret_cast<const float2*>(g.data + 2 * (long)row) : make_float2(0.f, 0.f);
+    in_loc = lv.x;
+    in_v = lv.y;
+    in_b = valid ? (int)((unsigned)row / (unsigned)g.N) : -1;
+    // rows 2*it + h of the d2 block: lane r reads column r of the traffic lane of car 2*it + h.  All
+    // exchanges first, then all loads from clamped addresses (no branch between them), so that the
+    // sixteen round trips overlap.
+    int b_it[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) b_it[it] = __shfl(in_b, 2 * it + h, 64);
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
-      const int b = __shfl(in_b, 2 * it + h, 64);
-      in_d2[it] = b >= 0 ? g.d2[(long)b * 32 + r] : 0.f;
+      const float dv = g.d2[(long)max(b_it[it], 0) * 32 + r];
+      in_d2[it] = b_it[it] >= 0 ? dv : 0.f;
     }
   };
   float* wl = lds + CAR_WAVE0 + wave * CAR_WAVE_FLOATS;
@@ -129,18 +135,20 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
     float4 v0[8], v2[4];
     request_w4<128, 64>(v0, g.w0, tid);
     request_w4<32, 128>(v2, g.w2, tid);
+    // biases and the narrow layers travel in the same round trip as the matrices
+    const float p_b0 = g.b0[tid & 127], p_b2 = g.b2[r], p_w4 = g.w4[r], p_b4 = g.b4[0];
     build_cat();                         // wave-private, under the weights' round trip
     commit_w4<128, 64>(W0s, 65, v0, tid);
     commit_w4<32, 128>(W2s, 129, v2, tid);
+    if (tid < 128) b0s[tid] = p_b0;
+    if (tid < 32) {
+      b2s[tid] = p_b2;
+      w4s[tid] = p_w4;
+      wlocs[tid] = wl_r;
+      blocs[tid] = bl_r;
+    }
+    if (tid == 0) b4s[0] = p_b4;
   }
-  if (tid < 128) b0s[tid] = g.b0[tid];
-  if (tid < 32) {
-    b2s[tid] = g.b2[tid];
-    w4s[tid] = g.w4[tid];
-    wlocs[tid] = g.wloc[tid];
-    blocs[tid] = g.bloc[tid];
-  }
-  if (tid == 0) b4s[0] = g.b4[0];
   __syncthreads();
   HHRL_STAMP(0, 1);
 
@@ -1108,22 +1116,41 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
       const int idx = u * 256 + tid, rr = idx >> 5, c = idx & 31;
       eps_r[u] = (c >= gd && c < 2 * gd && row0 + rr < g.B) ? g.eps[(long)(row0 + rr) * gd + c - gd] : 0.f;
     }
-    // dd2 of a traffic lane = sum of the per-(lane, car tile) partial rows of the car tiles its cars span
+    // dd2 of a traffic lane = sum of the per-(lane, car tile) partial rows of the car tiles its cars span,
+    // in tile order.  The first two tiles (all there are when N <= 33) are read from clamped addresses
+    // without a branch, so the eight round trips of a thread overlap; longer lanes loop over the rest.
     float dd2v[4];
+    {
+      const unsigned n = (unsigned)g.N;
+      float p0[4], p1[4];
+      unsigned t0s[4], t1s[4];
+      bool ok0[4], ok1[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = u * 256 + tid, rr = idx >> 5, c = idx & 31;
-      const int b = row0 + rr;
-      float sum = 0.f;
-      if (b < g.B) {
-        const unsigned n = (unsigned)g.N, lo = (unsigned)b * n;
+      for (int u = 0; u < 4; ++u) {
+        const int idx = u * 256 + tid, rr = idx >> 5, c = idx & 31;
+        const int b = row0 + rr;
+        const unsigned lo = (unsigned)b * n;
         const unsigned t0 = lo >> 5, t1 = (lo + n - 1) >> 5;
-        for (unsigned t = t0; t <= t1; ++t) {
-          const unsigned slot = (unsigned)b - (t * 32u) / n;
-          sum += g.dpart[((long)t * 32 + slot) * 32 + c];
-        }
+        ok0[u] = b < g.B;
+        ok1[u] = ok0[u] && t1 > t0;
+        t0s[u] = t0;
+        t1s[u] = t1;
+        const long a0 = ((long)t0 * 32 + ((unsigned)b - (t0 * 32u) / n)) * 32 + c;
+        const long a1 = ((long)(t0 + 1) * 32 + ((unsigned)b - ((t0 + 1) * 32u) / n)) * 32 + c;
+        p0[u] = g.dpart[ok0[u] ? a0 : c];
+        p1[u] = g.dpart[ok1[u] ? a1 : c];
       }
-      dd2v[u] = sum;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float sum = ok0[u] ? p0[u] : 0.f;
+        if (ok1[u]) sum += p1[u];
+        if (ok1[u] && t1s[u] > t0s[u] + 1) {
+          const int idx = u * 256 + tid, rr = idx >> 5, c = idx & 31;
+          const unsigned b = (unsigned)(row0 + rr);
+          for (unsigned t = t0s[u] + 2; t <= t1s[u]; ++t) sum += g.dpart[((long)t * 32 + (b - (t * 32u) / n)) * 32 + c];
+        }
+        dd2v[u] = sum;
+      }
     }
     actR.request(act_tile, tid);
     if (first) request_R(rR, g, tid);
@@ -1425,6 +1452,7 @@ static int vae_step_impl(float* params, float* grads, float* m, float* v, const 
                          float* loss, float* ws, void* stream) {
   HHRL_REQUIRE(params && grads && offsets && data && eps && loss && ws, "vae_train_step: null pointer");
   HHRL_REQUIRE(B > 0 && N > 0, "vae_train_step: bad shape B=%d N=%d", B, N);
+  HHRL_REQUIRE((long)B * N < (1L << 31) - 64, "vae_train_step: B*N = %ld cars exceed the 32-bit row index", (long)B * N);
   HHRL_REQUIRE(g == 2 || g == 4 || g == 8 || g == 16, "vae_train_step: latent size %d not in {2,4,8,16}", g);
   HHRL_REQUIRE((long)B * N < (1L << 31) - 64, "vae_train_step: B*N too large");
   static const long numel_w[NLAYER] = {32, 512, 4096, 8192, -64, -64, -128, 4096, 32, 8192, 4096, 32};

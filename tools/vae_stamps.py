@@ -51,5 +51,10 @@ def main():
             print("  %-34s %8d  %5.1f%%" % (labels[i], d, 100.0 * d / span))
 
 
+    if os.environ.get("HHRL_STAMPS_RAW"):
+        for k in range(3):
+            print("raw", k, [int(v - st[k, 0]) for v in st[k]])
+
+
 if __name__ == "__main__":
     main()
