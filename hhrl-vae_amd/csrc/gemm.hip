@@ -115,7 +115,8 @@ constexpr int SKC = 64;   // reduction elements staged per wave per chunk
 __device__ __forceinline__ void gemm_small_body(const GemmArgs& g, int bx, int by, int bz) {
   __shared__ float stage[4][2][SKC][33];
   __shared__ float part[4][32][33];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // in a scalar register: what depends on it is wave-uniform
   const int r = lane & 31, h = lane >> 5;
   const int i0 = by * 32, j0 = bx * 32;
   const int zbeg = bz * g.k_chunk;
@@ -130,29 +131,65 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& g, int bx, int b
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
+  // Rows of A beyond M and columns of B beyond N only feed output elements that are never stored, so
+  // their addresses are clamped to the last valid row / column instead of predicating every load, and
+  // k-strided operands are read pair by pair with the pointer held at the last full pair.  Only the
+  // reduction range needs exact values: the last element of an odd chunk and the zero row after it are
+  // written separately.
+  const int nra = min(32, g.M - i0), ncb = min(32, g.N - j0);
   for (int k0 = kbeg; k0 < kend; k0 += SKC) {
     const int kc = min(SKC, kend - k0);
     const int kc2 = (kc + 1) & ~1;
+    const int np = kc >> 1;                             // full (k, k+1) pairs in the chunk
     // Stage both operand chunks: every lane first issues all 64 of its loads (one exposed
     // memory latency per chunk), then writes them to LDS.  As[k][i] = A(i0+i, k0+k), Bs[k][j] = B(k0+k, j0+j).
-    float av[32], bv[32];
+    float av[32], bv[32], a_tail = 0.f, b_tail = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      av[i] = 0.f;
+      bv[i] = 0.f;
+    }
     if (g.a_kcontig) {
-      const long base = (long)i0 * g.a_si + (long)(k0 + lane) * g.a_sk;
+      if (lane < kc) {
+        const float* pa = g.A + (long)i0 * g.a_si + (k0 + lane);
 #pragma unroll
-      for (int i = 0; i < 32; ++i) av[i] = (lane < kc && i0 + i < g.M) ? g.A[base + (long)i * g.a_si] : 0.f;
+        for (int i = 0; i < 32; ++i) {
+          av[i] = *pa;
+          pa += (i + 1 < nra) ? g.a_si : 0;
+        }
+      }
     } else {
-      const long base = (long)(i0 + r) * g.a_si + (long)(k0 + h) * g.a_sk;
+      const float* row = g.A + (long)(i0 + min(r, nra - 1)) * g.a_si + (long)k0 * g.a_sk;
+      if (np > 0) {
+        const float* pa = row + h * g.a_sk;
 #pragma unroll
-      for (int t = 0; t < 32; ++t) av[t] = (2 * t + h < kc && i0 + r < g.M) ? g.A[base + (long)(2 * t) * g.a_sk] : 0.f;
+        for (int t = 0; t < 32; ++t) {
+          av[t] = *pa;
+          pa += (t + 1 < np) ? 2 * g.a_sk : 0;
+        }
+      }
+      if (kc & 1) a_tail = row[(long)(kc - 1) * g.a_sk];
     }
     if (g.b_kcontig) {
-      const long base = (long)(k0 + lane) * g.b_sk + (long)j0 * g.b_sj;
+      if (lane < kc) {
+        const float* pb = g.B + (long)j0 * g.b_sj + (k0 + lane);
 #pragma unroll
-      for (int j = 0; j < 32; ++j) bv[j] = (lane < kc && j0 + j < g.N) ? g.B[base + (long)j * g.b_sj] : 0.f;
+        for (int j = 0; j < 32; ++j) {
+          bv[j] = *pb;
+          pb += (j + 1 < ncb) ? g.b_sj : 0;
+        }
+      }
     } else {
-      const long base = (long)(k0 + h) * g.b_sk + (long)(j0 + r) * g.b_sj;
+      const float* col = g.B + (long)k0 * g.b_sk + (long)(j0 + min(r, ncb - 1)) * g.b_sj;
+      if (np > 0) {
+        const float* pb = col + h * g.b_sk;
 #pragma unroll
-      for (int t = 0; t < 32; ++t) bv[t] = (2 * t + h < kc && j0 + r < g.N) ? g.B[base + (long)(2 * t) * g.b_sk] : 0.f;
+        for (int t = 0; t < 32; ++t) {
+          bv[t] = *pb;
+          pb += (t + 1 < np) ? 2 * g.b_sk : 0;
+        }
+      }
+      if (kc & 1) b_tail = col[(long)(kc - 1) * g.b_sk];
     }
     if (g.a_kcontig) {
 #pragma unroll
@@ -160,6 +197,7 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& g, int bx, int b
     } else {
 #pragma unroll
       for (int t = 0; t < 32; ++t) As[2 * t + h][r] = av[t];
+      if (kc & 1) As[kc - 1 + h][r] = h == 0 ? a_tail : 0.f;
     }
     if (g.b_kcontig) {
 #pragma unroll
@@ -167,6 +205,7 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& g, int bx, int b
     } else {
 #pragma unroll
       for (int t = 0; t < 32; ++t) Bs[2 * t + h][r] = bv[t];
+      if (kc & 1) Bs[kc - 1 + h][r] = h == 0 ? b_tail : 0.f;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
