@@ -22,10 +22,10 @@ tot = sum(v['ms'] for v in rep.values()); nl = sum(v['launches'] for v in rep.va
 print(which, 'wall ms/update (profiling on)', 1e3*dt/K, 'gpu-kernel ms/update', tot/K, 'launches/update', nl/K)
 for k, v in sorted(rep.items(), key=lambda kv: -kv[1]['ms']): print('  %-32s %6.1f launches %8.3f ms/update  %6.1f us avg' % (k, v['launches']/K, v['ms']/K, 1e3*v['ms']/v['launches']))
 lib.hhrl_prof_reset()
-for ug in (False, True):
+for ug in (False, True, "auto"):
     net = mk(ug)
     net.memory[:n] = np.random.RandomState(1).uniform(0, 1, size=(n, net.fam.row_width)); net.pointer = n
-    for _ in range(40): net.learn()
+    for _ in range(80): net.learn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(100): net.learn()
