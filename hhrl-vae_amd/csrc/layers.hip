@@ -182,9 +182,12 @@ int hhrl_linear_backward(const float* x, int ldx, const float* w, const float* y
                        rows_per_block);
     HHRL_TRY(launch_status("act_grad_colsum_kernel"));
   }
-  if (dx) HHRL_TRY(gemm(dy, lddy, 1, w, K, 1, dx, lddx, M, K, N, nullptr, HHRL_ACT_NONE, dx_accumulate ? 1 : 0, st));
-  if (dw) HHRL_TRY(gemm(dy, 1, lddy, x, ldx, 1, dw, K, N, K, M, nullptr, HHRL_ACT_NONE, 2, st));
-  return HHRL_OK;
+  // input and weight gradient read the same dy and write different buffers: one launch for both
+  GemmArgs g[2];
+  int m = 0;
+  if (dx) g[m++] = gemm_args(dy, lddy, 1, w, K, 1, dx, lddx, M, K, N, nullptr, HHRL_ACT_NONE, dx_accumulate ? 1 : 0);
+  if (dw) g[m++] = gemm_args(dy, 1, lddy, x, ldx, 1, dw, K, N, K, M, nullptr, HHRL_ACT_NONE, 2);
+  return gemm_group(g, m, st);
 }
 
 int hhrl_linear_forward_group(const hhrl_linear_fwd_desc* d, int n, int M, void* stream) {
@@ -232,8 +235,16 @@ int hhrl_linear_backward_group(const hhrl_linear_bwd_desc* d, int n, int M, void
     hipLaunchKernelGGL(act_grad_colsum_group_kernel, grid, dim3(256), 0, st, ag, M, 16);
     HHRL_TRY(launch_status("act_grad_colsum_group_kernel"));
   }
-  // input gradients: layers that overwrite their dx first, then the ones that accumulate (they may share a dx)
-  GemmArgs g[kGemmGroupMax];
+  // Input gradients: layers that overwrite their dx first, then the ones that accumulate (they may share
+  // a dx).  The weight gradients read the same dy and write their own buffers, so they ride along with
+  // the first of those launches.
+  GemmArgs g[2 * kGemmGroupMax];
+  auto flush = [&](int m) -> int {
+    for (int at = 0; at < m; at += kGemmGroupMax)
+      HHRL_TRY(gemm_group(g + at, m - at < kGemmGroupMax ? m - at : kGemmGroupMax, st));
+    return HHRL_OK;
+  };
+  bool dw_done = false;
   for (int pass = 0; pass < 2; ++pass) {
     int m = 0;
     for (int i = 0; i < n; ++i) {
@@ -247,14 +258,16 @@ int hhrl_linear_backward_group(const hhrl_linear_bwd_desc* d, int n, int M, void
         for (int b = a + 1; b < m; ++b)
           HHRL_REQUIRE(g[a].C != g[b].C, "linear_backward_group: two layers accumulate into the same dx");
     }
-    HHRL_TRY(gemm_group(g, m, st));
+    if (!dw_done && (m > 0 || pass == 1)) {
+      for (int i = 0; i < n; ++i) {
+        const hhrl_linear_bwd_desc& l = d[i];
+        if (l.dw) g[m++] = gemm_args(l.dy, 1, l.lddy, l.x, l.ldx, 1, l.dw, l.K, l.N, l.K, M, nullptr, HHRL_ACT_NONE, 2);
+      }
+      dw_done = true;
+    }
+    HHRL_TRY(flush(m));
   }
-  int m = 0;
-  for (int i = 0; i < n; ++i) {
-    const hhrl_linear_bwd_desc& l = d[i];
-    if (l.dw) g[m++] = gemm_args(l.dy, 1, l.lddy, l.x, l.ldx, 1, l.dw, l.K, l.N, l.K, M, nullptr, HHRL_ACT_NONE, 2);
-  }
-  return gemm_group(g, m, st);
+  return HHRL_OK;
 }
 
 int hhrl_sum_pool(const float* in, int ldi, float* out, int ldo, int B, int N, int C, void* stream) {
