@@ -90,8 +90,16 @@ def agent_update_rates(device, steps: int) -> dict:
         rows = np.random.RandomState(3407).uniform(0, 1, size=(n_rows, net.fam.row_width))
         net.memory[:n_rows] = rows
         net.pointer = n_rows
-        for _ in range(30):                    # eager runs, then every (policy step, actor order) graph gets captured
+        n_orders = 1
+        for k in range(2, len(net.actors) + 1):
+            n_orders *= k
+        # warm up until every (policy step, actor order) launch chain has its final form (graph or eager);
+        # a chain needs six runs, a given actor order comes up once in 2 * n_orders updates
+        for it in range(60 * n_orders):
             net.learn()
+            forms = net.launch_forms()
+            if it >= 30 and len(forms) == 1 + n_orders and "tuning" not in forms.values():
+                break
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):

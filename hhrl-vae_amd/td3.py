@@ -543,6 +543,24 @@ class TD3Learner:
                 s.step()
         self.last_critic_loss = self._loss
 
+    def launch_forms(self) -> Dict[tuple, str]:
+        """(batch, policy step?, actor order) -> "graph", "eager" or "tuning" for every launch chain seen
+        so far; a benchmark warms up until none is "tuning" and every chain it expects has come up."""
+        out = {}
+        for key in self._seen:
+            if key in self._graphs:
+                form = "graph"
+            elif self.use_graph is False or self.group is not None:
+                form = "eager"
+            elif self.use_graph is True:
+                form = "tuning"
+            else:
+                form = "eager" if self._tune.get(key, {}).get("done") else "tuning"
+            if form == "graph" and self.use_graph == "auto" and not self._tune[key]["done"]:
+                form = "tuning"
+            out[key] = form
+        return out
+
     def _run_body(self, key, st, B: int, policy: bool, order: Sequence[int]) -> None:
         """Enqueues the update's kernels eagerly or as a captured HIP graph.
 

@@ -25,7 +25,10 @@ lib.hhrl_prof_reset()
 for ug in (False, True, "auto"):
     net = mk(ug)
     net.memory[:n] = np.random.RandomState(1).uniform(0, 1, size=(n, net.fam.row_width)); net.pointer = n
-    for _ in range(80): net.learn()
+    for it in range(800):
+        net.learn()
+        f = net.launch_forms()
+        if it >= 30 and len(f) == (2 if which == 'worker' else 7) and 'tuning' not in f.values(): break
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(100): net.learn()
