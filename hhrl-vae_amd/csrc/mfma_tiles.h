@@ -69,34 +69,35 @@ __device__ __forceinline__ void load_weight(float* img, int ld, const float* __r
 // Weight matrices [ROWS][COLS] (row-major, 16-byte aligned, COLS % 32 == 0) travel as float4 per thread.
 // Thread -> element map: a group of 32 threads takes a block of 4 rows x 32 columns, 8 threads per row.
 // Global reads stay in 128-byte runs, and with an image row stride of 1 mod 32 the four 4-byte LDS
-// writes of a float4 land in 32 different banks across the group.
-template <int ROWS, int COLS>
+// writes of a float4 land in 32 different banks across the group.  NT = threads that share the copy.
+template <int ROWS, int COLS, int NT = 256>
 struct W4Map {
-  static_assert(COLS % 32 == 0 && ROWS % 4 == 0 && ((ROWS / 4) * (COLS / 32)) % 8 == 0, "unsupported weight shape");
-  static constexpr int CB = COLS / 32, STEPS = (ROWS / 4) * CB / 8;
+  static constexpr int GROUPS = NT / 32;
+  static_assert(COLS % 32 == 0 && ROWS % 4 == 0 && ((ROWS / 4) * (COLS / 32)) % GROUPS == 0, "unsupported weight shape");
+  static constexpr int CB = COLS / 32, STEPS = (ROWS / 4) * CB / GROUPS;
   __device__ __forceinline__ static void pos(int tid, int u, int& row, int& col) {
-    const int blk = u * 8 + (tid >> 5), br = blk / CB, bc = blk % CB;
+    const int blk = u * GROUPS + (tid >> 5), br = blk / CB, bc = blk % CB;
     row = 4 * br + ((tid & 31) >> 3);
     col = 32 * bc + 4 * (tid & 7);
   }
 };
-template <int ROWS, int COLS, int STEPS>
+template <int ROWS, int COLS, int STEPS, int NT = 256>
 __device__ __forceinline__ void request_w4(float4 (&v)[STEPS], const float* __restrict__ w, int tid) {
-  static_assert(STEPS == W4Map<ROWS, COLS>::STEPS, "register array does not match the weight shape");
+  static_assert(STEPS == W4Map<ROWS, COLS, NT>::STEPS, "register array does not match the weight shape");
 #pragma unroll
-  for (int u = 0; u < W4Map<ROWS, COLS>::STEPS; ++u) {
+  for (int u = 0; u < STEPS; ++u) {
     int row, col;
-    W4Map<ROWS, COLS>::pos(tid, u, row, col);
+    W4Map<ROWS, COLS, NT>::pos(tid, u, row, col);
     v[u] = *reinterpret_cast<const float4*>(w + row * COLS + col);
   }
 }
-template <int ROWS, int COLS, int STEPS>
+template <int ROWS, int COLS, int STEPS, int NT = 256>
 __device__ __forceinline__ void commit_w4(float* img, int ld, const float4 (&v)[STEPS], int tid) {
-  static_assert(STEPS == W4Map<ROWS, COLS>::STEPS, "register array does not match the weight shape");
+  static_assert(STEPS == W4Map<ROWS, COLS, NT>::STEPS, "register array does not match the weight shape");
 #pragma unroll
-  for (int u = 0; u < W4Map<ROWS, COLS>::STEPS; ++u) {
+  for (int u = 0; u < STEPS; ++u) {
     int row, col;
-    W4Map<ROWS, COLS>::pos(tid, u, row, col);
+    W4Map<ROWS, COLS, NT>::pos(tid, u, row, col);
     float* p = img + row * ld + col;
     p[0] = v[u].x; p[1] = v[u].y; p[2] = v[u].z; p[3] = v[u].w;
   }

@@ -463,12 +463,12 @@ static_assert(LN_LDS_FLOATS * 4 <= 163840 - 64, "per-lane kernels must fit the 1
 constexpr int LN_ACT_FLOATS = LI_D2 - LI_H1;      // h1 | pooled | r1 | r2 | mean,logvar | z | d1, verbatim
 static_assert(LI_H1 % 4 == 0 && LN_ACT_FLOATS % 4 == 0, "activation images are copied 16 bytes at a time");
 constexpr int ACT_V4 = LN_ACT_FLOATS / 4;
-constexpr int ACT_PER_THREAD = (ACT_V4 + 255) / 256;
 
+template <int NT = 256>
 __device__ __forceinline__ void store_rows32(const float* img, float* dst, int row0, int B, int tid) {
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int idx = u * 256 + tid, rr = idx >> 5, c = idx & 31;
+  for (int u = 0; u < 1024 / NT; ++u) {
+    const int idx = u * NT + tid, rr = idx >> 5, c = idx & 31;
     if (row0 + rr < B) dst[(long)(row0 + rr) * 32 + c] = img[rr * 33 + c];
   }
 }
@@ -485,10 +485,11 @@ __device__ __forceinline__ float colsum32(const float* img, int ld, int col) {
 // ---- registers that carry global loads from request to LDS, grouped by when the chain needs them:
 //      group P (phi.2, rho.0, car states), group R (rho.2, heads), group D (decoder.0, decoder.2), biases.
 //      Every request of a tile is issued before the first LDS write, so the round trips overlap.
-struct RegsP { float4 rho0[4], phi2; float cars[4]; };
-struct RegsR { float4 rho2[8]; float head[8]; };
-struct RegsD { float4 dec2[4]; float dec0[8]; };
-struct RegsB { float bias[2]; };
+//      NT = threads of the workgroup that share the copies (256, or 512 when four more waves help with them).
+template <int NT> struct RegsP { float4 rho0[W4Map<128, 32, NT>::STEPS], phi2; float cars[1024 / NT]; };
+template <int NT> struct RegsR { float4 rho2[W4Map<64, 128, NT>::STEPS]; float head[2048 / NT]; };
+template <int NT> struct RegsD { float4 dec2[W4Map<32, 128, NT>::STEPS]; float dec0[2048 / NT]; };
+template <int NT> struct RegsB { float bias[512 / NT]; };
 
 __device__ __forceinline__ const float* lane_bias_src(const LaneArgs& g, int idx) {
   const int gd = g.g;
@@ -511,104 +512,114 @@ __device__ __forceinline__ void commit4(float* img, int ld, int i4, const float4
   p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
 }
 
-__device__ __forceinline__ void request_bias(RegsB& R, const LaneArgs& g, int tid) {
+template <int NT>
+__device__ __forceinline__ void request_bias(RegsB<NT>& R, const LaneArgs& g, int tid) {
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const float* src = lane_bias_src(g, u * 256 + tid);
+  for (int u = 0; u < 512 / NT; ++u) {
+    const float* src = lane_bias_src(g, u * NT + tid);
     R.bias[u] = src ? *src : 0.f;
   }
 }
-__device__ __forceinline__ void commit_bias(float* lds, const RegsB& R, int tid) {
+template <int NT>
+__device__ __forceinline__ void commit_bias(float* lds, const RegsB<NT>& R, int tid) {
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int idx = u * 256 + tid;
+  for (int u = 0; u < 512 / NT; ++u) {
+    const int idx = u * NT + tid;
     if (idx < LB_END) lds[LW_BIAS + idx] = R.bias[u];
   }
 }
 
-__device__ __forceinline__ void request_cars(float (&cars)[4], const LaneArgs& g, int row0, int tid) {
+template <int NT>
+__device__ __forceinline__ void request_cars(float (&cars)[1024 / NT], const LaneArgs& g, int row0, int tid) {
   const long base = (long)row0 * g.N * 2;
   const long lim = (long)g.B * g.N * 2;
   const int n = g.N <= STAGE_MAX_CARS ? 64 * g.N : 0;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int i = u * 256 + tid;
+  for (int u = 0; u < 1024 / NT; ++u) {
+    const int i = u * NT + tid;
     cars[u] = (i < n && base + i < lim) ? g.data[base + i] : 0.f;
   }
 }
-__device__ __forceinline__ void commit_cars(float* lds, const float (&cars)[4], const LaneArgs& g, int tid) {
+template <int NT>
+__device__ __forceinline__ void commit_cars(float* lds, const float (&cars)[1024 / NT], const LaneArgs& g, int tid) {
   const int n = g.N <= STAGE_MAX_CARS ? 64 * g.N : 0;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int i = u * 256 + tid;
+  for (int u = 0; u < 1024 / NT; ++u) {
+    const int i = u * NT + tid;
     if (i < n) lds[LI_CARS + i] = cars[u];
   }
 }
 
-__device__ __forceinline__ void request_P(RegsP& R, const LaneArgs& g, int row0, int tid) {
-  request_w4<128, 32>(R.rho0, g.w[RHO0], tid);
+template <int NT>
+__device__ __forceinline__ void request_P(RegsP<NT>& R, const LaneArgs& g, int row0, int tid) {
+  request_w4<128, 32, W4Map<128, 32, NT>::STEPS, NT>(R.rho0, g.w[RHO0], tid);
   R.phi2 = tid < 128 ? reinterpret_cast<const float4*>(g.w[PHI2])[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
-  request_cars(R.cars, g, row0, tid);
+  request_cars<NT>(R.cars, g, row0, tid);
 }
-__device__ __forceinline__ void commit_P(float* lds, const RegsP& R, const LaneArgs& g, int tid) {
-  commit_w4<128, 32>(lds + LW_RHO0, 33, R.rho0, tid);
+template <int NT>
+__device__ __forceinline__ void commit_P(float* lds, const RegsP<NT>& R, const LaneArgs& g, int tid) {
+  commit_w4<128, 32, W4Map<128, 32, NT>::STEPS, NT>(lds + LW_RHO0, 33, R.rho0, tid);
   if (tid < 128) commit4<16>(lds + LW_PHI2, 17, tid, R.phi2);
-  commit_cars(lds, R.cars, g, tid);
+  commit_cars<NT>(lds, R.cars, g, tid);
 }
 
-__device__ __forceinline__ void request_R(RegsR& R, const LaneArgs& g, int tid) {
-  request_w4<64, 128>(R.rho2, g.w[RHO2], tid);
+template <int NT>
+__device__ __forceinline__ void request_R(RegsR<NT>& R, const LaneArgs& g, int tid) {
+  request_w4<64, 128, W4Map<64, 128, NT>::STEPS, NT>(R.rho2, g.w[RHO2], tid);
   const int gd = g.g, nh = 128 * gd;                   // heads: 2g rows x 64
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int e = u * 256 + tid;
+  for (int u = 0; u < 2048 / NT; ++u) {
+    const int e = u * NT + tid;
     R.head[u] = e < nh ? (e < 64 * gd ? g.w[MEAN][e] : g.w[LOGVAR][e - 64 * gd]) : 0.f;
   }
 }
-__device__ __forceinline__ void commit_R(float* lds, const RegsR& R, const LaneArgs& g, int tid) {
-  commit_w4<64, 128>(lds + LW_RHO2, 129, R.rho2, tid);
+template <int NT>
+__device__ __forceinline__ void commit_R(float* lds, const RegsR<NT>& R, const LaneArgs& g, int tid) {
+  commit_w4<64, 128, W4Map<64, 128, NT>::STEPS, NT>(lds + LW_RHO2, 129, R.rho2, tid);
   const int gd = g.g, nh = 128 * gd;
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int e = u * 256 + tid;
+  for (int u = 0; u < 2048 / NT; ++u) {
+    const int e = u * NT + tid;
     if (e < nh) lds[LW_HEAD + (e >> 6) * 65 + (e & 63)] = R.head[u];
   }
-  for (int i = tid; i < 32 * 65; i += 256)             // rows >= 2g of the heads image are zero
+  for (int i = tid; i < 32 * 65; i += NT)              // rows >= 2g of the heads image are zero
     if (i / 65 >= 2 * gd) lds[LW_HEAD + i] = 0.f;
 }
 
-__device__ __forceinline__ void request_D(RegsD& R, const LaneArgs& g, int tid) {
-  request_w4<32, 128>(R.dec2, g.w[DEC2], tid);
+template <int NT>
+__device__ __forceinline__ void request_D(RegsD<NT>& R, const LaneArgs& g, int tid) {
+  request_w4<32, 128, W4Map<32, 128, NT>::STEPS, NT>(R.dec2, g.w[DEC2], tid);
   const int nd = 128 * g.g;                            // decoder.0: 128 rows x g
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int e = u * 256 + tid;
+  for (int u = 0; u < 2048 / NT; ++u) {
+    const int e = u * NT + tid;
     R.dec0[u] = e < nd ? g.w[DEC0][e] : 0.f;
   }
 }
-__device__ __forceinline__ void commit_D(float* lds, const RegsD& R, const LaneArgs& g, int tid) {
-  commit_w4<32, 128>(lds + LW_DEC2, 129, R.dec2, tid);
+template <int NT>
+__device__ __forceinline__ void commit_D(float* lds, const RegsD<NT>& R, const LaneArgs& g, int tid) {
+  commit_w4<32, 128, W4Map<32, 128, NT>::STEPS, NT>(lds + LW_DEC2, 129, R.dec2, tid);
   const int gd = g.g, nd = 128 * gd, lg = __ffs(gd) - 1;
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int e = u * 256 + tid;
+  for (int u = 0; u < 2048 / NT; ++u) {
+    const int e = u * NT + tid;
     if (e < nd) lds[LW_DEC0 + (e >> lg) * 17 + (e & (gd - 1))] = R.dec0[u];
   }
-  for (int i = tid; i < 128 * 17; i += 256)            // columns >= g of the decoder.0 image are zero
+  for (int i = tid; i < 128 * 17; i += NT)             // columns >= g of the decoder.0 image are zero
     if (i % 17 >= gd) lds[LW_DEC0 + i] = 0.f;
 }
 
 // A contiguous range of the saved activation images, 16 bytes per thread and step.
-template <int LO, int HI>
+template <int LO, int HI, int NT>
 struct ActRange {
   static_assert(LO % 4 == 0 && HI % 4 == 0, "image boundaries are multiples of 4 floats");
-  static constexpr int V4 = (HI - LO) / 4, STEPS = (V4 + 255) / 256;
+  static constexpr int V4 = (HI - LO) / 4, STEPS = (V4 + NT - 1) / NT;
   float4 v[STEPS];
   __device__ __forceinline__ void request(const float* act_tile, int tid) {
     const float4* src = reinterpret_cast<const float4*>(act_tile + (LO - LI_H1));
 #pragma unroll
     for (int u = 0; u < STEPS; ++u) {
-      const int i4 = u * 256 + tid;
+      const int i4 = u * NT + tid;
       v[u] = i4 < V4 ? src[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
@@ -616,14 +627,17 @@ struct ActRange {
     float4* dst = reinterpret_cast<float4*>(lds + LO);
 #pragma unroll
     for (int u = 0; u < STEPS; ++u) {
-      const int i4 = u * 256 + tid;
+      const int i4 = u * NT + tid;
       if (i4 < V4) dst[i4] = v[u];
     }
   }
 };
 
 // ------------------------------------------------------------------ forward
-__global__ __launch_bounds__(256, 1) void vae_lane_forward_kernel(LaneArgs g) {
+// NT = 256, or 512: four more waves share the copies into LDS and the element-wise phases (at one wave
+// per SIMD those are bound by instruction issue); the matrix phases stay on waves 0..3.
+template <int NT>
+__global__ __launch_bounds__(NT, 1) void vae_lane_forward_kernel(LaneArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31;
   const int rb = wave & 1, cb = wave >> 1;      // 16-row / 16-column block owned by this wave in 32x32 outputs
@@ -639,11 +653,12 @@ __global__ __launch_bounds__(256, 1) void vae_lane_forward_kernel(LaneArgs g) {
   float* Id1 = lds + LI_D1;
   float* Id2 = lds + LI_D2;
   const bool staged = g.N <= STAGE_MAX_CARS;
+  const bool mat = wave < 4;                      // this wave takes part in the matrix phases
   HHRL_STAMP(1, 0);
-  RegsB rB;
-  RegsP rP;
-  RegsR rR;
-  RegsD rD;
+  RegsB<NT> rB;
+  RegsP<NT> rP;
+  RegsR<NT> rR;
+  RegsD<NT> rD;
   // phi.0 of hidden unit tid & 15 (every element this thread computes in the phi.0 phase uses that unit)
   const float wa = g.w[PHI0][2 * (tid & 15)], wb = g.w[PHI0][2 * (tid & 15) + 1], bb = g.b[PHI0][tid & 15];
   request_bias(rB, g, tid);
@@ -660,20 +675,20 @@ __global__ __launch_bounds__(256, 1) void vae_lane_forward_kernel(LaneArgs g) {
     const int row0 = tile * 32;
     const bool first = tile == (int)blockIdx.x;
     if (!first) {                                // later tiles: the images of the previous tile are dead (barrier at loop end)
-      request_cars(rP.cars, g, row0, tid);
-      commit_cars(lds, rP.cars, g, tid);
+      request_cars<NT>(rP.cars, g, row0, tid);
+      commit_cars<NT>(lds, rP.cars, g, tid);
       __syncthreads();
     }
-    // the tile's reparameterisation noise, requested long before its phase: elements tid and tid + 256 of [32][16]
-    float eps_r[2];
+    // the tile's reparameterisation noise, requested long before its phase: elements tid (+ NT) of [32][16]
+    float eps_r[512 / NT];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int idx = u * 256 + tid, rr = idx >> 4, j = idx & 15;
+    for (int u = 0; u < 512 / NT; ++u) {
+      const int idx = u * NT + tid, rr = idx >> 4, j = idx & 15;
       eps_r[u] = (j < gd && row0 + rr < g.B) ? g.eps[(long)(row0 + rr) * gd + j] : 0.f;
     }
     HHRL_STAMP(1, 2);
     // ---- phi.0 + ReLU summed over each lane's cars
-    for (int idx = tid; idx < 32 * 16; idx += 256) {
+    for (int idx = tid; idx < 32 * 16; idx += NT) {
       const int rr = idx >> 4, k = idx & 15;
       const int b = row0 + rr;
       float s = 0.f;
@@ -686,7 +701,7 @@ __global__ __launch_bounds__(256, 1) void vae_lane_forward_kernel(LaneArgs g) {
     __syncthreads();
     HHRL_STAMP(1, 3);
     // ---- phi.2 on the summed hidden: pooled = W2 h1s + N b2
-    {
+    if (mat) {
       const f32x4 c = wave_mma16<16, 33, 1, 1, 17>(Ih1 + 16 * rb * 33, lds + LW_PHI2 + 16 * cb * 17, lane,
                                                    (float)g.N * bs[LB_PHI2 + 16 * cb + j16]);
       store_block16<33>(Ipool, 16 * rb, 16 * cb, c, lane);
@@ -694,7 +709,7 @@ __global__ __launch_bounds__(256, 1) void vae_lane_forward_kernel(LaneArgs g) {
     __syncthreads();
     HHRL_STAMP(1, 4);
     // ---- rho.0 (32 -> 128, ReLU): one 32-column tile per wave
-    {
+    if (mat) {
       f32x16 acc[1];
       acc[0] = splat(bs[LB_RHO0 + wave * 32 + r]);
       wave_mma<1, 32, 33, 1, 1, 33>(acc, Ipool, lds + LW_RHO0 + wave * 32 * 33, lane);
@@ -705,17 +720,19 @@ __global__ __launch_bounds__(256, 1) void vae_lane_forward_kernel(LaneArgs g) {
     __syncthreads();
     HHRL_STAMP(1, 5);
     // ---- rho.2 (128 -> 64): two 16x16 blocks per wave
+    if (mat) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int col0 = 32 * cb + 16 * t;
-      const f32x4 c = wave_mma16<128, 129, 1, 1, 129>(Ir1 + 16 * rb * 129, lds + LW_RHO2 + col0 * 129, lane,
-                                                      bs[LB_RHO2 + col0 + j16]);
-      store_block16<65>(Ir2, 16 * rb, col0, c, lane);
+      for (int t = 0; t < 2; ++t) {
+        const int col0 = 32 * cb + 16 * t;
+        const f32x4 c = wave_mma16<128, 129, 1, 1, 129>(Ir1 + 16 * rb * 129, lds + LW_RHO2 + col0 * 129, lane,
+                                                        bs[LB_RHO2 + col0 + j16]);
+        store_block16<65>(Ir2, 16 * rb, col0, c, lane);
+      }
     }
     __syncthreads();
     HHRL_STAMP(1, 6);
     // ---- heads (64 -> 2g; columns >= 2g come out as zero)
-    {
+    if (mat) {
       const f32x4 c = wave_mma16<64, 65, 1, 1, 65>(Ir2 + 16 * rb * 65, lds + LW_HEAD + 16 * cb * 65, lane,
                                                    bs[LB_HEAD + 16 * cb + j16]);
       store_block16<33>(Iml, 16 * rb, 16 * cb, c, lane);
@@ -724,8 +741,8 @@ __global__ __launch_bounds__(256, 1) void vae_lane_forward_kernel(LaneArgs g) {
     HHRL_STAMP(1, 7);
     // ---- reparameterisation z = mean + eps * exp(logvar / 2), zero-padded to 16 columns
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int idx = u * 256 + tid, rr = idx >> 4, j = idx & 15;
+    for (int u = 0; u < 512 / NT; ++u) {
+      const int idx = u * NT + tid, rr = idx >> 4, j = idx & 15;
       float zv = 0.f;
       if (j < gd && row0 + rr < g.B) zv = Iml[rr * 33 + j] + eps_r[u] * expf(0.5f * Iml[rr * 33 + gd + j]);
       Iz[rr * 17 + j] = zv;
@@ -733,7 +750,7 @@ __global__ __launch_bounds__(256, 1) void vae_lane_forward_kernel(LaneArgs g) {
     __syncthreads();
     HHRL_STAMP(1, 8);
     // ---- decoder.0 (g -> 128, ReLU)
-    {
+    if (mat) {
       f32x16 acc[1];
       acc[0] = splat(bs[LB_DEC0 + wave * 32 + r]);
       wave_mma<1, 16, 17, 1, 1, 17>(acc, Iz, lds + LW_DEC0 + wave * 32 * 17, lane);
@@ -744,7 +761,7 @@ __global__ __launch_bounds__(256, 1) void vae_lane_forward_kernel(LaneArgs g) {
     __syncthreads();
     HHRL_STAMP(1, 9);
     // ---- decoder.2 (128 -> 32)
-    {
+    if (mat) {
       const f32x4 c = wave_mma16<128, 129, 1, 1, 129>(Id1 + 16 * rb * 129, lds + LW_DEC2 + 16 * cb * 129, lane,
                                                       bs[LB_DEC2 + 16 * cb + j16]);
       store_block16<33>(Id2, 16 * rb, 16 * cb, c, lane);
@@ -752,13 +769,13 @@ __global__ __launch_bounds__(256, 1) void vae_lane_forward_kernel(LaneArgs g) {
     __syncthreads();
     HHRL_STAMP(1, 10);
     // ---- outputs: d2 rows for the per-car kernel, the activation images for the backward kernel
-    store_rows32(Id2, g.d2, row0, g.B, tid);
+    store_rows32<NT>(Id2, g.d2, row0, g.B, tid);
     {
       float4* dst = reinterpret_cast<float4*>(g.act + (long)tile * LN_ACT_FLOATS);
       const float4* src = reinterpret_cast<const float4*>(lds + LI_H1);
 #pragma unroll
-      for (int u = 0; u < ACT_PER_THREAD; ++u) {
-        const int i4 = u * 256 + tid;
+      for (int u = 0; u < (ACT_V4 + NT - 1) / NT; ++u) {
+        const int i4 = u * NT + tid;
         if (i4 < ACT_V4) dst[i4] = src[i4];
       }
     }
@@ -792,8 +809,8 @@ __global__ __launch_bounds__(256, 1) void vae_encode_kernel(EncArgs a) {
   float* Iml = lds + LI_ML;
   float* cnt = lds + LI_TMP;           // cars per lane of the tile
   {
-    RegsB rB;
-    RegsR rR;
+    RegsB<256> rB;
+    RegsR<256> rR;
     float4 rho0[4];
     request_bias(rB, g, tid);
     request_w4<128, 32>(rho0, g.w[RHO0], tid);
@@ -1015,8 +1032,11 @@ __global__ __launch_bounds__(256, 1) void vae_decode_kernel(DecArgs g) {
 // ------------------------------------------------------------------ backward
 // SINGLE: the grid covers every tile (one tile per workgroup, the case up to 8192 traffic lanes); a layer's
 // slab entries are then written right after the phase that completes them, under the later phases.
-template <bool SINGLE>
-__global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
+// NT = 256, or 512 (with SINGLE only: the multi-tile form needs the full register file per wave): four more
+// waves share the copies into LDS and the element-wise phases; the matrix phases stay on waves 0..3.
+template <bool SINGLE, int NT>
+__global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g) {
+  static_assert(NT == 256 || (NT == 512 && SINGLE), "helper waves only in the one-tile-per-workgroup form");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -1033,6 +1053,7 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
   float* Idml = lds + LI_DML;
   float* Itmp = lds + LI_TMP;   // dz, then t = dpooled * W_phi2
   const bool staged = g.N <= STAGE_MAX_CARS;
+  const bool mat = wave < 4;                      // this wave takes part in the matrix phases
   HHRL_STAMP(2, 0);
   // phi.0 of hidden unit tid & 15 (every element this thread handles in the phi.0 backward uses that unit)
   const float wa = g.w[PHI0][2 * (tid & 15)], wb = g.w[PHI0][2 * (tid & 15) + 1], bb = g.b[PHI0][tid & 15];
@@ -1096,13 +1117,13 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
     const int row0 = tile * 32;
     const bool first = SINGLE || tile == (int)blockIdx.x;
     // ---- request everything the tile needs in the order of use
-    RegsB rB;
-    RegsD rD;
-    RegsR rR;
-    RegsP rP;
-    ActRange<LI_ML, LI_D2> actD;      // mean|logvar, z, d1
-    ActRange<LI_R1, LI_ML> actR;      // r1, r2
-    ActRange<LI_H1, LI_R1> actP;      // h1, pooled
+    RegsB<NT> rB;
+    RegsD<NT> rD;
+    RegsR<NT> rR;
+    RegsP<NT> rP;
+    ActRange<LI_ML, LI_D2, NT> actD;  // mean|logvar, z, d1
+    ActRange<LI_R1, LI_ML, NT> actR;  // r1, r2
+    ActRange<LI_H1, LI_R1, NT> actP;  // h1, pooled
     const float* act_tile = g.act + (long)tile * LN_ACT_FLOATS;
     actD.request(act_tile, tid);
     if (first) {
@@ -1110,24 +1131,24 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
       request_D(rD, g, tid);
     }
     // the noise of the tile's logvar columns, for the latent phase: elements tid + 256 u of [32][32]
-    float eps_r[4];
+    float eps_r[1024 / NT];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = u * 256 + tid, rr = idx >> 5, c = idx & 31;
+    for (int u = 0; u < 1024 / NT; ++u) {
+      const int idx = u * NT + tid, rr = idx >> 5, c = idx & 31;
       eps_r[u] = (c >= gd && c < 2 * gd && row0 + rr < g.B) ? g.eps[(long)(row0 + rr) * gd + c - gd] : 0.f;
     }
     // dd2 of a traffic lane = sum of the per-(lane, car tile) partial rows of the car tiles its cars span,
     // in tile order.  The first two tiles (all there are when N <= 33) are read from clamped addresses
     // without a branch, so the eight round trips of a thread overlap; longer lanes loop over the rest.
-    float dd2v[4];
+    float dd2v[1024 / NT];
     {
       const unsigned n = (unsigned)g.N;
-      float p0[4], p1[4];
-      unsigned t0s[4], t1s[4];
-      bool ok0[4], ok1[4];
+      float p0[1024 / NT], p1[1024 / NT];
+      unsigned t0s[1024 / NT], t1s[1024 / NT];
+      bool ok0[1024 / NT], ok1[1024 / NT];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int idx = u * 256 + tid, rr = idx >> 5, c = idx & 31;
+      for (int u = 0; u < 1024 / NT; ++u) {
+        const int idx = u * NT + tid, rr = idx >> 5, c = idx & 31;
         const int b = row0 + rr;
         const unsigned lo = (unsigned)b * n;
         const unsigned t0 = lo >> 5, t1 = (lo + n - 1) >> 5;
@@ -1141,11 +1162,11 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
         p1[u] = g.dpart[ok1[u] ? a1 : c];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 1024 / NT; ++u) {
         float sum = ok0[u] ? p0[u] : 0.f;
         if (ok1[u]) sum += p1[u];
         if (ok1[u] && t1s[u] > t0s[u] + 1) {
-          const int idx = u * 256 + tid, rr = idx >> 5, c = idx & 31;
+          const int idx = u * NT + tid, rr = idx >> 5, c = idx & 31;
           const unsigned b = (unsigned)(row0 + rr);
           for (unsigned t = t0s[u] + 2; t <= t1s[u]; ++t) sum += g.dpart[((long)t * 32 + (b - (t * 32u) / n)) * 32 + c];
         }
@@ -1155,11 +1176,11 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
     actR.request(act_tile, tid);
     if (first) request_R(rR, g, tid);
     actP.request(act_tile, tid);
-    if (first) request_P(rP, g, row0, tid); else request_cars(rP.cars, g, row0, tid);
+    if (first) request_P(rP, g, row0, tid); else request_cars<NT>(rP.cars, g, row0, tid);
     // ---- and write it to LDS
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = u * 256 + tid;
+    for (int u = 0; u < 1024 / NT; ++u) {
+      const int idx = u * NT + tid;
       Id2[(idx >> 5) * 33 + (idx & 31)] = dd2v[u];
     }
     actD.commit(lds, tid);
@@ -1170,11 +1191,11 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
     actR.commit(lds, tid);
     if (first) commit_R(lds, rR, g, tid);
     actP.commit(lds, tid);
-    if (first) commit_P(lds, rP, g, tid); else commit_cars(lds, rP.cars, g, tid);
+    if (first) commit_P(lds, rP, g, tid); else commit_cars<NT>(lds, rP.cars, g, tid);
     __syncthreads();
     HHRL_STAMP(2, 1);
     // ---- decoder.2 backward: dW[32][128] += dd2^T d1, db, dd1 = (dd2 W) o relu'(d1) in place (column block `wave`)
-    {
+    if (mat) {
       f32x16 acc[1] = {aDec2};
       wave_mma<1, 32, 1, 33, 129, 1>(acc, Id2, Id1 + 32 * wave, lane);
       aDec2 = acc[0];
@@ -1189,11 +1210,11 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
         *p = *p > 0.f ? d[0][i] : 0.f;
       }
     }
-    if (SINGLE) write_dec2();
+    if (SINGLE && mat) write_dec2();
     __syncthreads();
     HHRL_STAMP(2, 2);
     // ---- decoder.0 backward: dW[128][g] += dd1^T z (row tile `wave`), db, dz = dd1 W (waves 0 and 1, 16 rows each)
-    {
+    if (mat) {
       f32x16 acc[1] = {aDec0};
       wave_mma<1, 32, 1, 129, 17, 1>(acc, Id1 + 32 * wave, Iz, lane);
       aDec0 = acc[0];
@@ -1204,13 +1225,13 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
         store_block16<33>(Itmp, 16 * wave, 0, c, lane);
       }
     }
-    if (SINGLE) write_dec0();
+    if (SINGLE && mat) write_dec0();
     __syncthreads();
     HHRL_STAMP(2, 3);
     // ---- latent gradient (KL + reparameterisation): dml = [dz + mean | dz*eps*0.5*std + 0.5*(exp(lv)-1) | 0...]
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = u * 256 + tid, rr = idx >> 5, c = idx & 31;
+    for (int u = 0; u < 1024 / NT; ++u) {
+      const int idx = u * NT + tid, rr = idx >> 5, c = idx & 31;
       float outv = 0.f;
       if (c < 2 * gd && row0 + rr < g.B) {
         const int j = c < gd ? c : c - gd;
@@ -1235,39 +1256,43 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
         f32x16 acc[1] = {aHead};
         wave_mma<1, 32, 1, 33, 65, 1>(acc, Idml, Ir2 + 32 * wave, lane);
         aHead = acc[0];
-      } else {
+      } else if (mat) {
         wave_mma<1, 32, 33, 1, 65, 1>(d, Idml, lds + LW_HEAD + 32 * (wave - 2), lane);
       }
       if (tid < 32) bHead += colsum32(Idml, 33, tid);
       __syncthreads();
-      if (wave >= 2) store_tile<65>(Ir2, 32 * (wave - 2), d[0], lane);
+      if (wave >= 2 && mat) store_tile<65>(Ir2, 32 * (wave - 2), d[0], lane);
     }
-    if (SINGLE) write_heads();
+    if (SINGLE && mat) write_heads();
     __syncthreads();
     HHRL_STAMP(2, 5);
     // ---- rho.2 backward: dW[64][128] += dr2^T r1 (two tiles per wave), db, dr1 = (dr2 W) o relu'(r1) in place
     {
-      const int it = wave >> 1, jt0 = (wave & 1) * 2;
-      f32x16 acc[2] = {aRho2a, aRho2b};
-      wave_mma<2, 32, 1, 65, 129, 1>(acc, Ir2 + 32 * it, Ir1 + 32 * jt0, lane);
-      aRho2a = acc[0];
-      aRho2b = acc[1];
-      if (tid < 64) bRho2 += colsum32(Ir2, 65, tid);
       f32x16 d[1];
       d[0] = splat(0.f);
-      wave_mma<1, 64, 65, 1, 129, 1>(d, Ir2, lds + LW_RHO2 + 32 * wave, lane);
+      if (mat) {
+        const int it = wave >> 1, jt0 = (wave & 1) * 2;
+        f32x16 acc[2] = {aRho2a, aRho2b};
+        wave_mma<2, 32, 1, 65, 129, 1>(acc, Ir2 + 32 * it, Ir1 + 32 * jt0, lane);
+        aRho2a = acc[0];
+        aRho2b = acc[1];
+        if (tid < 64) bRho2 += colsum32(Ir2, 65, tid);
+        wave_mma<1, 64, 65, 1, 129, 1>(d, Ir2, lds + LW_RHO2 + 32 * wave, lane);
+      }
       __syncthreads();                                  // every wave is done reading r1
+      if (mat) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float* p = Ir1 + drow(i, h) * 129 + 32 * wave + r;
-        *p = *p > 0.f ? d[0][i] : 0.f;
+        for (int i = 0; i < 16; ++i) {
+          float* p = Ir1 + drow(i, h) * 129 + 32 * wave + r;
+          *p = *p > 0.f ? d[0][i] : 0.f;
+        }
       }
     }
-    if (SINGLE) write_rho2();
+    if (SINGLE && mat) write_rho2();
     __syncthreads();
     HHRL_STAMP(2, 6);
     // ---- rho.0 backward: dW[128][32] += dr1^T pooled (row tile `wave`), db, dpooled = dr1 W (16x16 blocks) -> ml slot
-    {
+    if (mat) {
       f32x16 acc[1] = {aRho0};
       wave_mma<1, 32, 1, 129, 33, 1>(acc, Ir1 + 32 * wave, Ipool, lane);
       aRho0 = acc[0];
@@ -1275,7 +1300,7 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
       const f32x4 c = wave_mma16<128, 129, 1, 33, 1>(Ir1 + 16 * rb * 129, lds + LW_RHO0 + 16 * cb, lane, 0.f);
       store_block16<33>(Iml, 16 * rb, 16 * cb, c, lane);
     }
-    if (SINGLE) write_rho0();
+    if (SINGLE && mat) write_rho0();
     __syncthreads();
     HHRL_STAMP(2, 7);
     // ---- phi.2 backward on the summed hidden: dW[32][16] += dpooled^T h1s (wave 0), db = N colsum(dpooled) (wave 1),
@@ -1286,17 +1311,17 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
       aPhi2 = acc[0];
     } else if (wave == 1) {
       if (lane < 32) bPhi2 += (float)g.N * colsum32(Iml, 33, lane);
-    } else {
+    } else if (mat) {
       const f32x4 c = wave_mma16<32, 33, 1, 17, 1>(Iml + 16 * (wave - 2) * 33, lds + LW_PHI2, lane, 0.f);
       store_block16<33>(Itmp, 16 * (wave - 2), 0, c, lane);
     }
-    if (SINGLE) write_phi2();
+    if (SINGLE && mat) write_phi2();
     __syncthreads();
     HHRL_STAMP(2, 8);
     // ---- phi.0 backward: per (lane, hidden unit) walk the cars again and apply the ReLU mask
     {
       float* red = Ir2;       // [32][49] partial sums
-      for (int idx = tid; idx < 32 * 16; idx += 256) {
+      for (int idx = tid; idx < 32 * 16; idx += NT) {
         const int rr = idx >> 4, k = idx & 15;
         const int b = row0 + rr;
         float a0 = 0.f, a1 = 0.f, c = 0.f;
@@ -1340,10 +1365,15 @@ __global__ __launch_bounds__(256, 1) void vae_lane_backward_kernel(LaneArgs g) {
   }
   // KL partial of this workgroup
   klacc = wave_sum(klacc);
-  __shared__ float klred[4];
+  __shared__ float klred[NT / 64];
   if (lane == 0) klred[wave] = klacc;
   __syncthreads();
-  if (tid == 0) g.kl_part[blockIdx.x] = klred[0] + klred[1] + klred[2] + klred[3];
+  if (tid == 0) {
+    float kl = klred[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) kl += klred[w];
+    g.kl_part[blockIdx.x] = kl;
+  }
   HHRL_STAMP(2, 10);
 }
 
@@ -1476,19 +1506,24 @@ static int vae_step_impl(float* params, float* grads, float* m, float* v, const 
   const long rows = (long)B * N;
   const int ncar = grid_car(rows), nlane = grid_lane(B);
 
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(vae_car_fwd_bwd_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, CAR_LDS_FLOATS * 4);
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(vae_lane_forward_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS_FLOATS * 4);
-    hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(vae_lane_backward_kernel<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS_FLOATS * 4);
-    hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(vae_lane_backward_kernel<false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS_FLOATS * 4);
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess)
-      return fail(HHRL_ERR_HIP, "vae_train_step: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-    attr_done = true;
+  // Threads per workgroup of the per-lane kernels: 512 (four waves that only help with the copies into LDS
+  // and the element-wise phases) unless HHRL_LANE_THREADS=256 asks for the plain form (for comparisons).
+  static int lane_threads = 0;
+  if (lane_threads == 0) {
+    const char* e = getenv("HHRL_LANE_THREADS");
+    lane_threads = (e && atoi(e) == 256) ? 256 : 512;
+    const void* fns[] = {reinterpret_cast<const void*>(vae_car_fwd_bwd_kernel),
+                         reinterpret_cast<const void*>(vae_lane_forward_kernel<256>),
+                         reinterpret_cast<const void*>(vae_lane_forward_kernel<512>),
+                         reinterpret_cast<const void*>(vae_lane_backward_kernel<true, 256>),
+                         reinterpret_cast<const void*>(vae_lane_backward_kernel<true, 512>),
+                         reinterpret_cast<const void*>(vae_lane_backward_kernel<false, 256>)};
+    for (int i = 0; i < 6; ++i) {
+      if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (i == 0 ? CAR_LDS_FLOATS : LN_LDS_FLOATS) * 4) != hipSuccess) {
+        lane_threads = 0;
+        return fail(HHRL_ERR_HIP, "vae_train_step: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+      }
+    }
   }
 
   LaneArgs la;
@@ -1509,7 +1544,10 @@ static int vae_step_impl(float* params, float* grads, float* m, float* v, const 
   const double lane_macs = 16.0 * 2 * N + 512 + 4096 + 8192 + 128.0 * g + 128.0 * g + 4096;
   {
     ProfScope ps("vae_lane_forward_kernel", st, 2.0 * lane_macs * B, 4.0 * B * (2.0 * N + g + 32));
-    hipLaunchKernelGGL(vae_lane_forward_kernel, dim3(nlane), dim3(256), LN_LDS_FLOATS * 4, st, la);
+    if (lane_threads == 512)
+      hipLaunchKernelGGL(vae_lane_forward_kernel<512>, dim3(nlane), dim3(512), LN_LDS_FLOATS * 4, st, la);
+    else
+      hipLaunchKernelGGL(vae_lane_forward_kernel<256>, dim3(nlane), dim3(256), LN_LDS_FLOATS * 4, st, la);
     HHRL_TRY(launch_status("vae_lane_forward_kernel"));
   }
 
@@ -1536,10 +1574,12 @@ static int vae_step_impl(float* params, float* grads, float* m, float* v, const 
   }
   {
     ProfScope ps("vae_lane_backward_kernel", st, 4.0 * lane_macs * B, 4.0 * B * (2.0 * N + g + 32));
-    if (nlane >= la.tiles)
-      hipLaunchKernelGGL(vae_lane_backward_kernel<true>, dim3(nlane), dim3(256), LN_LDS_FLOATS * 4, st, la);
+    if (nlane >= la.tiles && lane_threads == 512)
+      hipLaunchKernelGGL((vae_lane_backward_kernel<true, 512>), dim3(nlane), dim3(512), LN_LDS_FLOATS * 4, st, la);
+    else if (nlane >= la.tiles)
+      hipLaunchKernelGGL((vae_lane_backward_kernel<true, 256>), dim3(nlane), dim3(256), LN_LDS_FLOATS * 4, st, la);
     else
-      hipLaunchKernelGGL(vae_lane_backward_kernel<false>, dim3(nlane), dim3(256), LN_LDS_FLOATS * 4, st, la);
+      hipLaunchKernelGGL((vae_lane_backward_kernel<false, 256>), dim3(nlane), dim3(256), LN_LDS_FLOATS * 4, st, la);
     HHRL_TRY(launch_status("vae_lane_backward_kernel"));
   }
   {
