@@ -1086,12 +1086,20 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g) {
   };
   auto write_heads = [&]() {
     if (wave < 2) {
-      const int col = 32 * wave + r;
+      // rows < g belong to to_mean, rows g..2g-1 to to_logvar (g is a power of two: a register quad of four
+      // consecutive rows never straddles the two); register quads past row 2g hold nothing
+      float* wm = slab + g.off.w[MEAN] + 32 * wave + r;
+      float* wl = slab + g.off.w[LOGVAR] + 32 * wave + r;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = drow(i, h);
-        if (row < gd) slab[g.off.w[MEAN] + (long)row * 64 + col] = aHead[i];
-        else if (row < 2 * gd) slab[g.off.w[LOGVAR] + (long)(row - gd) * 64 + col] = aHead[i];
+      for (int qd = 0; qd < 4; ++qd) {
+        if (8 * qd < 2 * gd) {                           // wave-uniform
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int row = e + 8 * qd + 4 * h;
+            float* dst = row < gd ? wm + row * 64 : wl + (row - gd) * 64;
+            if (row < 2 * gd) *dst = aHead[4 * qd + e];
+          }
+        }
       }
     }
     if (tid < gd) slab[g.off.b[MEAN] + tid] = bHead;
