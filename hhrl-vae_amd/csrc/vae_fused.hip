@@ -58,6 +58,7 @@ struct CarArgs {
   long rows;          // B*N
   int N, tiles;
   float recon_scale;
+  int vec4;           // slab rows and the func.0 / func.2 weight offsets are 16-byte aligned
 };
 
 constexpr int CAR_W0 = 0;                         // [128][65]
@@ -367,8 +368,21 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
         for (int i = 0; i < 16; ++i) mine[(it * 32 + drow(i, h)) * 64 + jt * 32 + r] = dW0[it][jt][i];
   }
   __syncthreads();
-  for (int i = tid; i < Q0; i += 256)
-    slab[g.off.w[FUNC0] + i] = (lds[i] + lds[Q0 + i]) + (lds[2 * Q0 + i] + lds[3 * Q0 + i]);
+  auto sum4 = [](const float4& a, const float4& b, const float4& c, const float4& d) {
+    return make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+  };
+  if (g.vec4) {                                      // 16-byte aligned slab and offsets (wave-uniform): four elements per access
+    const float4* q = reinterpret_cast<const float4*>(lds);
+    float4* dst = reinterpret_cast<float4*>(slab + g.off.w[FUNC0]);
+#pragma unroll
+    for (int u = 0; u < Q0 / 1024; ++u) {
+      const int i = u * 256 + tid;
+      dst[i] = sum4(q[i], q[Q0 / 4 + i], q[2 * (Q0 / 4) + i], q[3 * (Q0 / 4) + i]);
+    }
+  } else {
+    for (int i = tid; i < Q0; i += 256)
+      slab[g.off.w[FUNC0] + i] = (lds[i] + lds[Q0 + i]) + (lds[2 * Q0 + i] + lds[3 * Q0 + i]);
+  }
   __syncthreads();
   HHRL_STAMP(0, 11);
   constexpr int B_W2 = 0, B_B0 = 4096, B_B2 = B_B0 + 128, B_W4 = B_B2 + 32, B_B4 = B_W4 + 32;
@@ -395,7 +409,17 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
   }
   __syncthreads();
   auto all4 = [&](int i) { return (lds[i] + lds[Q1 + i]) + (lds[2 * Q1 + i] + lds[3 * Q1 + i]); };
-  for (int i = tid; i < 4096; i += 256) slab[g.off.w[FUNC2] + i] = all4(B_W2 + i);
+  if (g.vec4) {
+    const float4* q = reinterpret_cast<const float4*>(lds + B_W2);
+    float4* dst = reinterpret_cast<float4*>(slab + g.off.w[FUNC2]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = u * 256 + tid;
+      dst[i] = sum4(q[i], q[Q1 / 4 + i], q[2 * (Q1 / 4) + i], q[3 * (Q1 / 4) + i]);
+    }
+  } else {
+    for (int i = tid; i < 4096; i += 256) slab[g.off.w[FUNC2] + i] = all4(B_W2 + i);
+  }
   if (tid < 128) slab[g.off.b[FUNC0] + tid] = all4(B_B0 + tid);
   if (tid < 32) {
     slab[g.off.b[FUNC2] + tid] = all4(B_B2 + tid);
@@ -1574,6 +1598,7 @@ static int vae_step_impl(float* params, float* grads, float* m, float* v, const 
   ca.N = N;
   ca.tiles = (int)((rows + 31) / 32);
   ca.recon_scale = recon_scale;
+  ca.vec4 = (reinterpret_cast<uintptr_t>(w.slab) % 16 == 0 && n_flat % 4 == 0 && off.w[FUNC0] % 4 == 0 && off.w[FUNC2] % 4 == 0) ? 1 : 0;
   {
     // forward + input-gradient + weight-gradient products of loc/func.0/func.2/func.4: 3 * 2 * 12352 flop per car
     ProfScope ps("vae_car_fwd_bwd_kernel", st, 6.0 * (8192 + 4096 + 32 + 32) * rows, 4.0 * (2.0 * rows + 64.0 * B));
