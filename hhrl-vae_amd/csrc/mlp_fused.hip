@@ -57,92 +57,103 @@ __device__ __forceinline__ void wave_mma_rt(f32x16 (&acc)[TJ], const float* a, c
   }
 }
 
-// ---- staging helpers: every global load of a stage is issued before its first LDS write
+// ---- staging helpers: every global load of a stage is issued before its first LDS write.
+//      NT = threads of the workgroup: 256, or 512 when four more waves share the copies (at one wave per
+//      SIMD the copies are bound by instruction issue); the matrix phases stay on waves 0..3.
+template <int NT>
 struct StageW {
-  float4 w2[16];       // [128][128]
-  float4 w3[4];        // [N3][128], rows >= N3 zero
+  float4 w2[W4Map<H, H, NT>::STEPS];        // [128][128]
+  float4 w3[W4Map<NMAX, H, NT>::STEPS];     // [N3][128], rows >= N3 zero
 };
-__device__ __forceinline__ void request_w23(StageW& R, const Net& g, int tid) {
-  request_w4<H, H>(R.w2, g.w2, tid);
+template <int NT>
+__device__ __forceinline__ void request_w23(StageW<NT>& R, const Net& g, int tid) {
+  request_w4<H, H, W4Map<H, H, NT>::STEPS, NT>(R.w2, g.w2, tid);
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < W4Map<NMAX, H, NT>::STEPS; ++u) {
     int row, col;
-    W4Map<NMAX, H>::pos(tid, u, row, col);
+    W4Map<NMAX, H, NT>::pos(tid, u, row, col);
     R.w3[u] = row < g.N3 ? *reinterpret_cast<const float4*>(g.w3 + row * H + col) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
-__device__ __forceinline__ void commit_w23(float* lds, const StageW& R, int tid) {
-  commit_w4<H, H>(lds + L_W2, H + 1, R.w2, tid);
-  commit_w4<NMAX, H>(lds + L_W3, H + 1, R.w3, tid);
+template <int NT>
+__device__ __forceinline__ void commit_w23(float* lds, const StageW<NT>& R, int tid) {
+  commit_w4<H, H, W4Map<H, H, NT>::STEPS, NT>(lds + L_W2, H + 1, R.w2, tid);
+  commit_w4<NMAX, H, W4Map<NMAX, H, NT>::STEPS, NT>(lds + L_W3, H + 1, R.w3, tid);
 }
 // W1 [128][K0] (any K0 <= 64) and the x tile [32][K0]: element-wise, zero padding up to the even width K0p
+template <int NT>
 __device__ __forceinline__ void stage_w1_x(float* lds, const Net& g, int row0, int M, int tid, bool want_w1) {
   const int K0 = g.K0, K0p = (K0 + 7) & ~7;
   if (want_w1) {
-    for (int base = 0; base < H * K0p; base += 8 * 256) {
+    for (int base = 0; base < H * K0p; base += 8 * NT) {
       float v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int e = base + u * 256 + tid, rr = e / K0p, c = e - rr * K0p;
+        const int e = base + u * NT + tid, rr = e / K0p, c = e - rr * K0p;
         v[u] = (e < H * K0p && c < K0) ? g.w1[rr * K0 + c] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int e = base + u * 256 + tid, rr = e / K0p, c = e - rr * K0p;
+        const int e = base + u * NT + tid, rr = e / K0p, c = e - rr * K0p;
         if (e < H * K0p) lds[L_W1 + rr * (KMAX + 1) + c] = v[u];
       }
     }
   }
-  float v[8];
+  float v[2048 / NT];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int e = u * 256 + tid, rr = e / K0p, c = e - rr * K0p;
+  for (int u = 0; u < 2048 / NT; ++u) {
+    const int e = u * NT + tid, rr = e / K0p, c = e - rr * K0p;
     v[u] = (e < 32 * K0p && c < K0 && row0 + rr < M) ? g.x[(long)(row0 + rr) * g.ldx + c] : 0.f;
   }
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int e = u * 256 + tid, rr = e / K0p, c = e - rr * K0p;
+  for (int u = 0; u < 2048 / NT; ++u) {
+    const int e = u * NT + tid, rr = e / K0p, c = e - rr * K0p;
     if (e < 32 * K0p) lds[L_X + rr * (KMAX + 1) + c] = v[u];
   }
 }
 // a [32][128] tile of a row-major [M][128] matrix <-> an image with row stride 129
-__device__ __forceinline__ void request_rows128(float4 (&v)[4], const float* src, int row0, int M, int tid) {
+template <int NT, int STEPS>
+__device__ __forceinline__ void request_rows128(float4 (&v)[STEPS], const float* src, int row0, int M, int tid) {
+  static_assert(STEPS == W4Map<32, H, NT>::STEPS, "register array does not match the tile");
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < STEPS; ++u) {
     int row, col;
-    W4Map<32, H>::pos(tid, u, row, col);
+    W4Map<32, H, NT>::pos(tid, u, row, col);
     v[u] = row0 + row < M ? *reinterpret_cast<const float4*>(src + (long)(row0 + row) * H + col) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
+template <int NT>
 __device__ __forceinline__ void store_rows128(const float* img, float* dst, int row0, int M, int tid) {
 #pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    const int e = u * 256 + tid, rr = e >> 7, c = e & 127;
+  for (int u = 0; u < 4096 / NT; ++u) {
+    const int e = u * NT + tid, rr = e >> 7, c = e & 127;
     if (row0 + rr < M) dst[(long)(row0 + rr) * H + c] = img[rr * (H + 1) + c];
   }
 }
 
 // ------------------------------------------------------------------ forward
-__global__ __launch_bounds__(256, 1) void mlp3_forward_kernel(NetGroup grp, int M) {
+template <int NT>
+__global__ __launch_bounds__(NT, 1) void mlp3_forward_kernel(NetGroup grp, int M) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const Net& g = grp.in[blockIdx.y];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const bool mat = wave < 4;                      // this wave takes part in the matrix phases
   const int row0 = blockIdx.x * 32;
   const int K0p = (g.K0 + 7) & ~7;
   float* bs = lds + L_B;
   {
-    StageW R;
+    StageW<NT> R;
     request_w23(R, g, tid);
     const float b1 = tid < H ? g.b1[tid] : (tid < 2 * H ? g.b2[tid - H] : 0.f);
     const float b3 = tid < g.N3 ? g.b3[tid] : 0.f;
-    stage_w1_x(lds, g, row0, M, tid, true);
+    stage_w1_x<NT>(lds, g, row0, M, tid, true);
     commit_w23(lds, R, tid);
-    bs[tid] = b1;
+    if (tid < 2 * H) bs[tid] = b1;
     if (tid < NMAX) bs[2 * H + tid] = b3;
   }
   __syncthreads();
   // ---- layer 1 (K0 -> 128, ReLU): one 32-column tile per wave
-  {
+  if (mat) {
     f32x16 acc[1];
     acc[0] = splat(bs[32 * wave + r]);
     wave_mma_rt<1, KMAX + 1, 1, 1, KMAX + 1>(acc, lds + L_X, lds + L_W1 + 32 * wave * (KMAX + 1), lane, K0p);
@@ -152,7 +163,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_forward_kernel(NetGroup grp, int 
   }
   __syncthreads();
   // ---- layer 2 (128 -> 128, ReLU)
-  {
+  if (mat) {
     f32x16 acc[1];
     acc[0] = splat(bs[H + 32 * wave + r]);
     wave_mma<1, H, H + 1, 1, 1, H + 1>(acc, lds + L_A1, lds + L_W2 + 32 * wave * (H + 1), lane);
@@ -162,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_forward_kernel(NetGroup grp, int 
   }
   __syncthreads();
   // ---- layer 3 (128 -> N3 <= 32, act3): one 16x16 block per wave, straight to global memory
-  {
+  if (mat) {
     const int rb = wave & 1, cb = wave >> 1, j = lane & 15, q = lane >> 4;
     const f32x4 c = wave_mma16<H, H + 1, 1, 1, H + 1>(lds + L_A2 + 16 * rb * (H + 1), lds + L_W3 + 16 * cb * (H + 1), lane,
                                                      bs[2 * H + 16 * cb + j]);
@@ -174,17 +185,22 @@ __global__ __launch_bounds__(256, 1) void mlp3_forward_kernel(NetGroup grp, int 
     }
   }
   if (g.h1 != nullptr) {
-    store_rows128(lds + L_A1, g.h1, row0, M, tid);
-    store_rows128(lds + L_A2, g.h2, row0, M, tid);
+    store_rows128<NT>(lds + L_A1, g.h1, row0, M, tid);
+    store_rows128<NT>(lds + L_A2, g.h2, row0, M, tid);
   }
   (void)h;
 }
 
 // ------------------------------------------------------------------ backward
-__global__ __launch_bounds__(256, 1) void mlp3_backward_kernel(NetGroup grp, int M) {
+// With helper waves (NT == 512) waves 4..7 share the copies and own the bias gradients (thread T_B + column).
+template <int NT>
+__global__ __launch_bounds__(NT, 1) void mlp3_backward_kernel(NetGroup grp, int M) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const Net& g = grp.in[blockIdx.y];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const bool mat = wave < 4;                      // this wave takes part in the matrix phases
+  constexpr int T_B = NT == 512 ? 256 : 0;
+  const int bcol = tid - T_B;                     // bias-gradient column of this thread (if in range)
   const int row0 = blockIdx.x * 32;
   const int K0 = g.K0, K0p = (K0 + 7) & ~7, N3 = g.N3;
   const bool pg = g.gw1 != nullptr;            // parameter gradients wanted
@@ -197,16 +213,16 @@ __global__ __launch_bounds__(256, 1) void mlp3_backward_kernel(NetGroup grp, int
   float* A2 = lds + L_A2;     // h2, then its gradient
   float* D3 = lds + L_Y;      // gradient at the pre-activation of layer 3, columns >= N3 zero
   {
-    StageW R;
-    float4 a1[4], a2[4];
+    StageW<NT> R;
+    float4 a1[W4Map<32, H, NT>::STEPS], a2[W4Map<32, H, NT>::STEPS];
     request_w23(R, g, tid);
-    request_rows128(a1, g.h1, row0, M, tid);
-    request_rows128(a2, g.h2, row0, M, tid);
+    request_rows128<NT>(a1, g.h1, row0, M, tid);
+    request_rows128<NT>(a2, g.h2, row0, M, tid);
     // gradient at the output through act3
-    float d3[4];
+    float d3[1024 / NT];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = u * 256 + tid, rr = e >> 5, c = e & 31;
+    for (int u = 0; u < 1024 / NT; ++u) {
+      const int e = u * NT + tid, rr = e >> 5, c = e & 31;
       float v = 0.f;
       if (c < N3 && row0 + rr < M) {
         v = g.dy ? g.dy[(long)(row0 + rr) * g.lddy + c] : g.dy_const;
@@ -214,25 +230,25 @@ __global__ __launch_bounds__(256, 1) void mlp3_backward_kernel(NetGroup grp, int
       }
       d3[u] = v;
     }
-    stage_w1_x(lds, g, row0, M, tid, want_dx);
+    stage_w1_x<NT>(lds, g, row0, M, tid, want_dx);
     commit_w23(lds, R, tid);
-    commit_w4<32, H>(A1, H + 1, a1, tid);
-    commit_w4<32, H>(A2, H + 1, a2, tid);
+    commit_w4<32, H, W4Map<32, H, NT>::STEPS, NT>(A1, H + 1, a1, tid);
+    commit_w4<32, H, W4Map<32, H, NT>::STEPS, NT>(A2, H + 1, a2, tid);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = u * 256 + tid;
+    for (int u = 0; u < 1024 / NT; ++u) {
+      const int e = u * NT + tid;
       D3[(e >> 5) * 33 + (e & 31)] = d3[u];
     }
   }
   __syncthreads();
   // ---- layer 3: db3, dW3 [N3][128] += D3^T h2, dh2 = (D3 W3) o relu'(h2) in place (column block `wave`)
-  {
+  if (pg && bcol >= 0 && bcol < N3) {
+    float s = 0.f;
+    for (int rr = 0; rr < 32; ++rr) s += D3[rr * 33 + bcol];
+    unsafeAtomicAdd(&g.gb3[bcol], s);
+  }
+  if (mat) {
     if (pg) {
-      if (tid < N3) {
-        float s = 0.f;
-        for (int rr = 0; rr < 32; ++rr) s += D3[rr * 33 + tid];
-        unsafeAtomicAdd(&g.gb3[tid], s);
-      }
       f32x16 acc[1];
       acc[0] = splat(0.f);
       wave_mma<1, 32, 1, 33, H + 1, 1>(acc, D3, A2 + 32 * wave, lane);
@@ -255,39 +271,43 @@ __global__ __launch_bounds__(256, 1) void mlp3_backward_kernel(NetGroup grp, int
   __syncthreads();
   // ---- layer 2: db2, dW2 [128][128] += dh2^T h1 (row tile `wave`), dh1 = (dh2 W2) o relu'(h1) in place
   {
-    if (pg) {
-      if (tid < H) {
-        float s = 0.f;
-        for (int rr = 0; rr < 32; ++rr) s += A2[rr * (H + 1) + tid];
-        unsafeAtomicAdd(&g.gb2[tid], s);
-      }
-      f32x16 acc[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = splat(0.f);
-      wave_mma<4, 32, 1, H + 1, H + 1, 1>(acc, A2 + 32 * wave, A1, lane);
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) unsafeAtomicAdd(&g.gw2[(32 * wave + drow(i, h)) * H + 32 * t + r], acc[t][i]);
+    if (pg && bcol >= 0 && bcol < H) {
+      float s = 0.f;
+      for (int rr = 0; rr < 32; ++rr) s += A2[rr * (H + 1) + bcol];
+      unsafeAtomicAdd(&g.gb2[bcol], s);
     }
     f32x16 d[1];
     d[0] = splat(0.f);
-    wave_mma<1, H, H + 1, 1, H + 1, 1>(d, A2, W2s + 32 * wave, lane);
-    __syncthreads();                                   // every wave is done reading h1
+    if (mat) {
+      if (pg) {
+        f32x16 acc[4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      float* p = A1 + drow(i, h) * (H + 1) + 32 * wave + r;
-      *p = *p > 0.f ? d[0][i] : 0.f;
+        for (int t = 0; t < 4; ++t) acc[t] = splat(0.f);
+        wave_mma<4, 32, 1, H + 1, H + 1, 1>(acc, A2 + 32 * wave, A1, lane);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) unsafeAtomicAdd(&g.gw2[(32 * wave + drow(i, h)) * H + 32 * t + r], acc[t][i]);
+      }
+      wave_mma<1, H, H + 1, 1, H + 1, 1>(d, A2, W2s + 32 * wave, lane);
+    }
+    __syncthreads();                                   // every wave is done reading h1
+    if (mat) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float* p = A1 + drow(i, h) * (H + 1) + 32 * wave + r;
+        *p = *p > 0.f ? d[0][i] : 0.f;
+      }
     }
   }
   __syncthreads();
   // ---- layer 1: db1, dW1 [128][K0] += dh1^T x (row tile `wave`), dx = dh1 W1 (16x16 blocks)
-  if (pg) {
-    if (tid < H) {
-      float s = 0.f;
-      for (int rr = 0; rr < 32; ++rr) s += A1[rr * (H + 1) + tid];
-      unsafeAtomicAdd(&g.gb1[tid], s);
-    }
+  if (pg && bcol >= 0 && bcol < H) {
+    float s = 0.f;
+    for (int rr = 0; rr < 32; ++rr) s += A1[rr * (H + 1) + bcol];
+    unsafeAtomicAdd(&g.gb1[bcol], s);
+  }
+  if (pg && mat) {
     f32x16 acc[2];
     acc[0] = splat(0.f);
     acc[1] = splat(0.f);
@@ -302,26 +322,34 @@ __global__ __launch_bounds__(256, 1) void mlp3_backward_kernel(NetGroup grp, int
     }
   }
   if (want_dx) {
-    const int rb = wave & 1, j = lane & 15, q = lane >> 4;
-    for (int cb = wave >> 1; 16 * cb < K0p; cb += 2) {
-      const f32x4 c = wave_mma16<H, H + 1, 1, KMAX + 1, 1>(A1 + 16 * rb * (H + 1), W1s + 16 * cb, lane, 0.f);
-      const int col = 16 * cb + j;
+    // 16x16 blocks of dx: over waves 0..3, or over the four helper waves when there are any (they are idle here)
+    const int xw = NT == 512 ? wave - 4 : wave;
+    if (xw >= 0) {
+      const int rb = xw & 1, j = lane & 15, q = lane >> 4;
+      for (int cb = xw >> 1; 16 * cb < K0p; cb += 2) {
+        const f32x4 c = wave_mma16<H, H + 1, 1, KMAX + 1, 1>(A1 + 16 * rb * (H + 1), W1s + 16 * cb, lane, 0.f);
+        const int col = 16 * cb + j;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int row = row0 + 16 * rb + 4 * q + e;
-        if (row < M && col < K0) g.dx[(long)row * g.lddx + col] = c[e];
+        for (int e = 0; e < 4; ++e) {
+          const int row = row0 + 16 * rb + 4 * q + e;
+          if (row < M && col < K0) g.dx[(long)row * g.lddx + col] = c[e];
+        }
       }
     }
   }
 }
 
+// Threads per workgroup: 512 (four helper waves) unless HHRL_MLP_THREADS=256 asks for the plain form.
+static int g_threads = 0;
 static int set_attrs() {
-  static bool done = false;
-  if (done) return HHRL_OK;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp3_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L_END * 4) != hipSuccess ||
-      hipFuncSetAttribute(reinterpret_cast<const void*>(mlp3_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L_END * 4) != hipSuccess)
-    return fail(HHRL_ERR_HIP, "mlp3: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-  done = true;
+  if (g_threads != 0) return HHRL_OK;
+  const void* fns[] = {reinterpret_cast<const void*>(mlp3_forward_kernel<256>), reinterpret_cast<const void*>(mlp3_forward_kernel<512>),
+                       reinterpret_cast<const void*>(mlp3_backward_kernel<256>), reinterpret_cast<const void*>(mlp3_backward_kernel<512>)};
+  for (int i = 0; i < 4; ++i)
+    if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, L_END * 4) != hipSuccess)
+      return fail(HHRL_ERR_HIP, "mlp3: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+  const char* e = getenv("HHRL_MLP_THREADS");
+  g_threads = (e && atoi(e) == 256) ? 256 : 512;
   return HHRL_OK;
 }
 
@@ -381,7 +409,10 @@ int hhrl_mlp3_forward_group(const hhrl_mlp3_desc* d, int n, int M, void* stream)
   double flops = 0.0;
   for (int i = 0; i < n; ++i) flops += 2.0 * M * ((double)d[i].K0 * H + (double)H * H + (double)H * d[i].N3);
   ProfScope ps("mlp3_forward_kernel", st, flops, 0.0);
-  hipLaunchKernelGGL(mlp3_forward_kernel, dim3(ceil_div(M, 32), n), dim3(256), L_END * 4, st, grp, M);
+  if (g_threads == 512)
+    hipLaunchKernelGGL(mlp3_forward_kernel<512>, dim3(ceil_div(M, 32), n), dim3(512), L_END * 4, st, grp, M);
+  else
+    hipLaunchKernelGGL(mlp3_forward_kernel<256>, dim3(ceil_div(M, 32), n), dim3(256), L_END * 4, st, grp, M);
   return launch_status("mlp3_forward_kernel");
 }
 
@@ -393,7 +424,10 @@ int hhrl_mlp3_backward_group(const hhrl_mlp3_desc* d, int n, int M, void* stream
   double flops = 0.0;
   for (int i = 0; i < n; ++i) flops += 4.0 * M * ((double)d[i].K0 * H + (double)H * H + (double)H * d[i].N3);
   ProfScope ps("mlp3_backward_kernel", st, flops, 0.0);
-  hipLaunchKernelGGL(mlp3_backward_kernel, dim3(ceil_div(M, 32), n), dim3(256), L_END * 4, st, grp, M);
+  if (g_threads == 512)
+    hipLaunchKernelGGL(mlp3_backward_kernel<512>, dim3(ceil_div(M, 32), n), dim3(512), L_END * 4, st, grp, M);
+  else
+    hipLaunchKernelGGL(mlp3_backward_kernel<256>, dim3(ceil_div(M, 32), n), dim3(256), L_END * 4, st, grp, M);
   return launch_status("mlp3_backward_kernel");
 }
 
