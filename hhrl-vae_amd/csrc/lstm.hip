@@ -85,9 +85,21 @@ struct StepFwdInst {
 struct StepFwdGroup { StepFwdInst in[kMaxInst]; };
 constexpr int kMaxObsPad = 64;      // widest per-step observation the fused step kernel stages
 
+// Threads per workgroup of the forward step: 512 unless HHRL_LSTM_THREADS=256 asks for the plain form.
+static int step_threads() {
+  static int nt = 0;
+  if (nt == 0) {
+    const char* e = getenv("HHRL_LSTM_THREADS");
+    nt = (e && atoi(e) == 256) ? 256 : 512;
+  }
+  return nt;
+}
 static long step_fwd_lds_bytes(int H) { return 4L * (2L * 32 * (H + kMaxObsPad + 1) + 4 * 32 * 33); }
 
-__global__ __launch_bounds__(256) void lstm_step_forward_kernel(StepFwdGroup grp, int B, int H) {
+// NT threads: 256, or 512 when four more waves share the copies into LDS (bound by instruction issue at
+// one wave per SIMD); the product and the gate epilogue stay on waves 0..3.
+template <int NT>
+__global__ __launch_bounds__(NT) void lstm_step_forward_kernel(StepFwdGroup grp, int B, int H) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const StepFwdInst& g = grp.in[blockIdx.z];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -102,11 +114,11 @@ __global__ __launch_bounds__(256) void lstm_step_forward_kernel(StepFwdGroup grp
   {
     // every global load is issued before the first LDS write
     const int hq = H >> 2;               // float4 per state / W_hh row (H % 32 == 0 on this path)
-    float4 v[4], wv[4];
+    float4 v[1024 / NT], wv[1024 / NT];
     if (has_h) {
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {            // 32*hq float4 each, <= 4 per thread for H <= 128
-        const int i4 = it * 256 + tid;
+      for (int it = 0; it < 1024 / NT; ++it) {    // 32*hq float4 each, <= 1024 / NT per thread for H <= 128
+        const int i4 = it * NT + tid;
         const int rr = i4 / hq, c4 = i4 - rr * hq;
         const bool in = i4 < 32 * hq;
         v[it] = (in && row0 + rr < B) ? reinterpret_cast<const float4*>(g.h_prev + (long)(row0 + rr) * H)[c4]
@@ -117,10 +129,10 @@ __global__ __launch_bounds__(256) void lstm_step_forward_kernel(StepFwdGroup grp
       }
     }
     // x_t tile (32 rows x o, contiguous in time-major storage) and the 32 W_ih rows: 32*opad elements each, <= 8 per thread
-    float xv[8], wi[8];
+    float xv[2048 / NT], wi[2048 / NT];
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int e = it * 256 + tid;
+    for (int it = 0; it < 2048 / NT; ++it) {
+      const int e = it * NT + tid;
       const int rr = e / opad, c = e - rr * opad;
       const bool in = e < 32 * opad && c < o;
       xv[it] = (in && row0 + rr < B) ? g.x[(long)(row0 + rr) * o + c] : 0.f;
@@ -129,8 +141,8 @@ __global__ __launch_bounds__(256) void lstm_step_forward_kernel(StepFwdGroup grp
     }
     if (has_h) {
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int i4 = it * 256 + tid;
+      for (int it = 0; it < 1024 / NT; ++it) {
+        const int i4 = it * NT + tid;
         const int rr = i4 / hq, c4 = i4 - rr * hq;
         if (i4 < 32 * hq) {
           float* p = Ah + rr * ld + 4 * c4;
@@ -141,8 +153,8 @@ __global__ __launch_bounds__(256) void lstm_step_forward_kernel(StepFwdGroup grp
       }
     }
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int e = it * 256 + tid;
+    for (int it = 0; it < 2048 / NT; ++it) {
+      const int e = it * NT + tid;
       const int rr = e / opad, c = e - rr * opad;
       if (e < 32 * opad) {
         Ah[rr * ld + H + c] = xv[it];
@@ -154,17 +166,19 @@ __global__ __launch_bounds__(256) void lstm_step_forward_kernel(StepFwdGroup grp
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  {
+  if (wave < 4) {
     const int kb = has_h ? 0 : H, len = (has_h ? H : 0) + opad;   // a multiple of 8
     const int kq = len >> 2;                                      // this wave's quarter of the reduction
     const float* ap = Ah + r * ld + kb + wave * kq + h;
     const float* bp = Wq + r * ld + kb + wave * kq + h;
     for (int k = 0; k < kq; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k], bp[k], acc, 0, 0, 0);
   }
+  if (wave < 4) {
 #pragma unroll
-  for (int i = 0; i < 16; ++i) part[(wave * 32 + drow16(i, h)) * 33 + r] = acc[i];
+    for (int i = 0; i < 16; ++i) part[(wave * 32 + drow16(i, h)) * 33 + r] = acc[i];
+  }
   __syncthreads();
-  {
+  if (wave < 4) {
     const int rr = tid >> 3, j = tid & 7;
     const int b = row0 + rr, u = u0 + j;
     if (b < B && u < H) {
@@ -370,7 +384,9 @@ __global__ __launch_bounds__(256) void colsum2_kernel(ColsumGroup grp, int ld, i
 static int set_step_attrs(int H) {
   static int done_for = -1;
   if (done_for >= H) return HHRL_OK;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_forward_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)step_fwd_lds_bytes(H)) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_forward_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)step_fwd_lds_bytes(H)) != hipSuccess ||
       hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)step_bwd_lds_bytes(H)) != hipSuccess)
@@ -483,8 +499,12 @@ int hhrl_lstm_forward_group(const hhrl_lstm_desc* d, int n, int B, int T, int H,
     auto launch = [&](int count) -> int {
       ProfScope ps("lstm_step_forward_kernel", st, 2.0 * B * G * (double)(t > 0 ? H + omax : omax) * count,
                    4.0 * count * (B * (2.0 * G + 4.0 * H) + (double)G * H));
-      hipLaunchKernelGGL(lstm_step_forward_kernel, dim3(sgrid_base.x, sgrid_base.y, count), dim3(256), step_fwd_lds_bytes(H), st,
-                         sg, B, H);
+      if (step_threads() == 512)
+        hipLaunchKernelGGL(lstm_step_forward_kernel<512>, dim3(sgrid_base.x, sgrid_base.y, count), dim3(512), step_fwd_lds_bytes(H), st,
+                           sg, B, H);
+      else
+        hipLaunchKernelGGL(lstm_step_forward_kernel<256>, dim3(sgrid_base.x, sgrid_base.y, count), dim3(256), step_fwd_lds_bytes(H), st,
+                           sg, B, H);
       launched += count;
       return launch_status("lstm_step_forward_kernel");
     };
