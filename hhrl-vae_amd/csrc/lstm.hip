@@ -274,7 +274,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 static int step_bwd_lda(int H) { return 4 * H + 4; }       // row stride of the dgates image: 4 mod 32 banks, 16-byte rows
 static long step_bwd_lds_bytes(int H) { return 4L * (16L * step_bwd_lda(H) + 4L * H * 17 + 4 * 16 * 17); }
 
-__global__ __launch_bounds__(256) void lstm_step_backward_kernel(StepBwdGroup grp, int B, int H) {
+template <int NT>
+__global__ __launch_bounds__(NT) void lstm_step_backward_kernel(StepBwdGroup grp, int B, int H) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const StepBwdInst& g = grp.in[blockIdx.z];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -284,14 +285,15 @@ __global__ __launch_bounds__(256) void lstm_step_backward_kernel(StepBwdGroup gr
   float* Wt = Dg + 16 * lda;              // [4H][17]    W_hh[k][u0 + j]
   float* part = Wt + G4 * 17;             // [4][16][17]
   {
-    // 16-byte loads, 8 + 8 per thread for H = 128, all issued before the LDS writes
+    // 16-byte loads, 2048 / NT + 2048 / NT per thread for H = 128, all issued before the LDS writes
     const int a4 = 16 * H;                // float4 count of the dgates tile (16 rows x 4H)
     const int n4 = G4 * 4;                // W_hh[k][u0 .. u0+15]: 4 float4 per row k
-    for (int base = 0; base < a4; base += 8 * 256) {
-      float4 v[8], wv[8];
+    constexpr int PER = 2048 / NT;
+    for (int base = 0; base < a4; base += PER * NT) {
+      float4 v[PER], wv[PER];
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int i4 = base + it * 256 + tid;
+      for (int it = 0; it < PER; ++it) {
+        const int i4 = base + it * NT + tid;
         const int rr = i4 / H, c4 = i4 - rr * H;
         v[it] = (i4 < a4 && row0 + rr < B) ? reinterpret_cast<const float4*>(g.dgates_t + (long)(row0 + rr) * G4)[c4]
                                            : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -300,8 +302,8 @@ __global__ __launch_bounds__(256) void lstm_step_backward_kernel(StepBwdGroup gr
                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int i4 = base + it * 256 + tid;
+      for (int it = 0; it < PER; ++it) {
+        const int i4 = base + it * NT + tid;
         const int rr = i4 / H, c4 = i4 - rr * H;
         if (i4 < a4) *reinterpret_cast<float4*>(Dg + rr * lda + 4 * c4) = v[it];
         const int k = i4 >> 2, w4 = i4 & 3;
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(256) void lstm_step_backward_kernel(StepBwdGroup gr
     }
   }
   __syncthreads();
-  {
+  if (wave < 4) {
     // wave `wave` reduces gate `wave`: k in [wave*H, (wave+1)*H), two accumulation chains
     const int i = lane & 15, q = lane >> 4;
     const float* ap = Dg + i * lda + wave * H + q;
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(256) void lstm_step_backward_kernel(StepBwdGroup gr
     for (int e = 0; e < 4; ++e) part[(wave * 16 + 4 * q + e) * 17 + i] = c0[e] + c1[e];
   }
   __syncthreads();
-  {
+  if (wave < 4) {
     const int rr = tid >> 4, j = tid & 15;
     const int b = row0 + rr, u = u0 + j;
     if (b < B && u < H) {
@@ -388,7 +390,9 @@ static int set_step_attrs(int H) {
                           (int)step_fwd_lds_bytes(H)) != hipSuccess ||
       hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_forward_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)step_fwd_lds_bytes(H)) != hipSuccess ||
-      hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+      hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_backward_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)step_bwd_lds_bytes(H)) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_backward_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)step_bwd_lds_bytes(H)) != hipSuccess)
     return fail(HHRL_ERR_HIP, "lstm: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
   done_for = H;
@@ -600,7 +604,11 @@ int hhrl_lstm_backward_group(const hhrl_lstm_desc* d, int n, int B, int T, int H
                              t > 1 ? w[i].cbuf + (long)(t - 1) * BH : nullptr, w[i].cbuf + (long)t * BH, w[i].dc,
                              w[i].dgates + (long)(t - 1) * B * G};
     ProfScope ps("lstm_step_backward_kernel", st, 2.0 * B * G * H * n, 4.0 * n * (B * (3.0 * G + 4.0 * H) + (double)G * H));
-    hipLaunchKernelGGL(lstm_step_backward_kernel, dim3(ceil_div(H, 16), ceil_div(B, 16), n), dim3(256), step_bwd_lds_bytes(H), st,
+    if (step_threads() == 512)
+      hipLaunchKernelGGL(lstm_step_backward_kernel<512>, dim3(ceil_div(H, 16), ceil_div(B, 16), n), dim3(512), step_bwd_lds_bytes(H), st,
+                       sg, B, H);
+    else
+      hipLaunchKernelGGL(lstm_step_backward_kernel<256>, dim3(ceil_div(H, 16), ceil_div(B, 16), n), dim3(256), step_bwd_lds_bytes(H), st,
                        sg, B, H);
     HHRL_TRY(launch_status("lstm_step_backward_kernel"));
   }
