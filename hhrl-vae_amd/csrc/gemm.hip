@@ -106,23 +106,26 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
 }
 
 // Latency-oriented variant for small outputs (batch-64 agent updates, LSTM steps).
-// One workgroup = one 32x32 output tile; its four waves each take a quarter of
-// the reduction range, staging their operand chunks in wave-private LDS (no
-// workgroup barrier in the loop), and the four partial tiles are summed in LDS
-// in wave order.  Many small workgroups instead of a few long-running ones.
-constexpr int SKC = 64;   // reduction elements staged per wave per chunk
-
+// One workgroup = one 32x32 output tile; its NW waves (4 or 8) each take a share of the reduction range,
+// staging their operand chunks in wave-private LDS (no workgroup barrier in the loop), and the partial
+// tiles are summed in LDS in a fixed order.  Many small workgroups instead of a few long-running ones.
+// The staging is bound by instruction issue, so eight waves (two per SIMD, 32-element chunks) halve it.
+template <int NW>
 __device__ __forceinline__ void gemm_small_body(const GemmArgs& g, int bx, int by, int bz) {
-  __shared__ float stage[4][2][SKC][33];
-  __shared__ float part[4][32][33];
+  constexpr int SKC = NW == 4 ? 64 : 32;            // reduction elements staged per wave per chunk
+  constexpr int RPL = SKC / 2;                      // operand elements per lane per chunk: 64 lanes x RPL = 32 x SKC
+  constexpr int NT = 64 * NW;
+  __shared__ float stage[NW][2][SKC][33];
+  __shared__ float part[NW][32][33];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // in a scalar register: what depends on it is wave-uniform
   const int r = lane & 31, h = lane >> 5;
+  const int kl = lane & (SKC - 1), hf = lane / SKC; // k-contiguous staging: lane -> (k of the chunk, half of the 32 rows)
   const int i0 = by * 32, j0 = bx * 32;
   const int zbeg = bz * g.k_chunk;
   const int zend = min(g.K, zbeg + g.k_chunk);
   // this wave's share of [zbeg, zend), a multiple of 2 except at the end
-  const int span = (((zend - zbeg + 3) / 4) + 1) & ~1;
+  const int span = (((zend - zbeg + NW - 1) / NW) + 1) & ~1;
   const int kbeg = min(zend, zbeg + wave * span), kend = min(zend, kbeg + span);
   float (*As)[33] = stage[wave][0];
   float (*Bs)[33] = stage[wave][1];
@@ -141,21 +144,22 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& g, int bx, int b
     const int kc = min(SKC, kend - k0);
     const int kc2 = (kc + 1) & ~1;
     const int np = kc >> 1;                             // full (k, k+1) pairs in the chunk
-    // Stage both operand chunks: every lane first issues all 64 of its loads (one exposed
-    // memory latency per chunk), then writes them to LDS.  As[k][i] = A(i0+i, k0+k), Bs[k][j] = B(k0+k, j0+j).
-    float av[32], bv[32], a_tail = 0.f, b_tail = 0.f;
+    // Stage both operand chunks: every lane first issues all of its loads (one exposed memory latency
+    // per chunk), then writes them to LDS.  As[k][i] = A(i0+i, k0+k), Bs[k][j] = B(k0+k, j0+j).
+    float av[RPL], bv[RPL], a_tail = 0.f, b_tail = 0.f;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
+    for (int i = 0; i < RPL; ++i) {
       av[i] = 0.f;
       bv[i] = 0.f;
     }
     if (g.a_kcontig) {
-      if (lane < kc) {
-        const float* pa = g.A + (long)i0 * g.a_si + (k0 + lane);
+      if (kl < kc) {
+        const int first = hf * RPL;                     // this lane's rows: first .. first + RPL - 1
+        const float* pa = g.A + (long)(i0 + min(first, nra - 1)) * g.a_si + (k0 + kl);
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
+        for (int i = 0; i < RPL; ++i) {
           av[i] = *pa;
-          pa += (i + 1 < nra) ? g.a_si : 0;
+          pa += (first + i + 1 < nra) ? g.a_si : 0;
         }
       }
     } else {
@@ -163,7 +167,7 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& g, int bx, int b
       if (np > 0) {
         const float* pa = row + h * g.a_sk;
 #pragma unroll
-        for (int t = 0; t < 32; ++t) {
+        for (int t = 0; t < RPL; ++t) {
           av[t] = *pa;
           pa += (t + 1 < np) ? 2 * g.a_sk : 0;
         }
@@ -171,12 +175,13 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& g, int bx, int b
       if (kc & 1) a_tail = row[(long)(kc - 1) * g.a_sk];
     }
     if (g.b_kcontig) {
-      if (lane < kc) {
-        const float* pb = g.B + (long)j0 * g.b_sj + (k0 + lane);
+      if (kl < kc) {
+        const int first = hf * RPL;
+        const float* pb = g.B + (long)(j0 + min(first, ncb - 1)) * g.b_sj + (k0 + kl);
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
+        for (int j = 0; j < RPL; ++j) {
           bv[j] = *pb;
-          pb += (j + 1 < ncb) ? g.b_sj : 0;
+          pb += (first + j + 1 < ncb) ? g.b_sj : 0;
         }
       }
     } else {
@@ -184,7 +189,7 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& g, int bx, int b
       if (np > 0) {
         const float* pb = col + h * g.b_sk;
 #pragma unroll
-        for (int t = 0; t < 32; ++t) {
+        for (int t = 0; t < RPL; ++t) {
           bv[t] = *pb;
           pb += (t + 1 < np) ? 2 * g.b_sk : 0;
         }
@@ -193,18 +198,18 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& g, int bx, int b
     }
     if (g.a_kcontig) {
 #pragma unroll
-      for (int i = 0; i < 32; ++i) As[lane][i] = av[i];
+      for (int i = 0; i < RPL; ++i) As[kl][hf * RPL + i] = av[i];
     } else {
 #pragma unroll
-      for (int t = 0; t < 32; ++t) As[2 * t + h][r] = av[t];
+      for (int t = 0; t < RPL; ++t) As[2 * t + h][r] = av[t];
       if (kc & 1) As[kc - 1 + h][r] = h == 0 ? a_tail : 0.f;
     }
     if (g.b_kcontig) {
 #pragma unroll
-      for (int j = 0; j < 32; ++j) Bs[lane][j] = bv[j];
+      for (int j = 0; j < RPL; ++j) Bs[kl][hf * RPL + j] = bv[j];
     } else {
 #pragma unroll
-      for (int t = 0; t < 32; ++t) Bs[2 * t + h][r] = bv[t];
+      for (int t = 0; t < RPL; ++t) Bs[2 * t + h][r] = bv[t];
       if (kc & 1) Bs[kc - 1 + h][r] = h == 0 ? b_tail : 0.f;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -216,18 +221,18 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& g, int bx, int b
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  // when k-contiguous staging left rows of the chunk beyond kc untouched they were zero-filled above
 #pragma unroll
   for (int i = 0; i < 16; ++i) part[wave][(i & 3) + 8 * (i >> 2) + 4 * h][r] = acc[i];
   __syncthreads();
-  // fixed-order sum of the four partial tiles, epilogue, store: thread -> (row = tid/8 + 32*u..., col)
+  // fixed-order sum of the partial tiles (pairs first), epilogue, store
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int idx = u * 256 + tid;
+  for (int u = 0; u < 1024 / NT; ++u) {
+    const int idx = u * NT + tid;
     const int row = idx >> 5, col = idx & 31;
     const int gi = i0 + row, gj = j0 + col;
     if (gi >= g.M || gj >= g.N) continue;
     float v = (part[0][row][col] + part[1][row][col]) + (part[2][row][col] + part[3][row][col]);
+    if (NW == 8) v += (part[4][row][col] + part[5][row][col]) + (part[6][row][col] + part[7][row][col]);
     float* c = g.C + (long)gi * g.ldc + gj;
     if (g.mode == 2) {
       unsafeAtomicAdd(c, v);
@@ -239,15 +244,27 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& g, int bx, int b
   }
 }
 
-__global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) { gemm_small_body(g, blockIdx.x, blockIdx.y, blockIdx.z); }
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_small_kernel(GemmArgs g) { gemm_small_body<NW>(g, blockIdx.x, blockIdx.y, blockIdx.z); }
 
 // Several independent small products in one launch: blockIdx.z = instance * splits + reduction slice.
 // The grid is sized for the largest instance; workgroups outside an instance's tile range leave at once.
-__global__ __launch_bounds__(256) void gemm_small_group_kernel(GemmGroup grp) {
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_small_group_kernel(GemmGroup grp) {
   const int inst = blockIdx.z / grp.splits, bz = blockIdx.z - inst * grp.splits;
   const GemmArgs& g = grp.g[inst];
   if ((int)blockIdx.x * 32 >= g.N || (int)blockIdx.y * 32 >= g.M || bz * g.k_chunk >= g.K) return;
-  gemm_small_body(g, blockIdx.x, blockIdx.y, bz);
+  gemm_small_body<NW>(g, blockIdx.x, blockIdx.y, bz);
+}
+
+// Waves per workgroup of the small kernels: 8 unless HHRL_GEMM_WAVES=4 asks for the four-wave form.
+static int small_waves() {
+  static int nw = 0;
+  if (nw == 0) {
+    const char* e = getenv("HHRL_GEMM_WAVES");
+    nw = (e && atoi(e) == 4) ? 4 : 8;
+  }
+  return nw;
 }
 
 GemmArgs gemm_args(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj, float* C, long ldc,
@@ -291,7 +308,8 @@ int gemm_group(const GemmArgs* gs, int n, hipStream_t st) {
   }
   dim3 grid(ceil_div(max_n, 32), ceil_div(max_m, 32), n * grp.splits);
   ProfScope ps("gemm_small_group_kernel", st, flops, bytes);
-  hipLaunchKernelGGL(gemm_small_group_kernel, grid, dim3(256), 0, st, grp);
+  if (small_waves() == 8) hipLaunchKernelGGL(gemm_small_group_kernel<8>, grid, dim3(512), 0, st, grp);
+  else hipLaunchKernelGGL(gemm_small_group_kernel<4>, grid, dim3(256), 0, st, grp);
   return launch_status("gemm_small_group_kernel");
 }
 
@@ -319,7 +337,8 @@ static int gemm_one(GemmArgs g, hipStream_t st) {
     }
     dim3 grid(ceil_div(N, 32), ceil_div(M, 32), gz);
     ProfScope ps("gemm_small_kernel", st, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + (double)M * N));
-    hipLaunchKernelGGL(gemm_small_kernel, grid, dim3(256), 0, st, g);
+    if (small_waves() == 8) hipLaunchKernelGGL(gemm_small_kernel<8>, grid, dim3(512), 0, st, g);
+    else hipLaunchKernelGGL(gemm_small_kernel<4>, grid, dim3(256), 0, st, g);
     return launch_status("gemm_small_kernel");
   }
   const int TM = M > 1024 ? 2 : 1;
