@@ -163,7 +163,7 @@ def test_vae_full_size_vs_oracle(B, N, g):
 
 
 @pytest.mark.parametrize("B,N,g", [(1, 1, 2), (3, 1, 4), (31, 7, 4), (33, 7, 8), (64, 7, 16), (5, 33, 4), (2, 59, 2),
-                                   (257, 5, 4), (1000, 3, 16), (4096, 7, 4), (4096, 30, 4), (2048, 59, 8), (9000, 2, 4)])
+                                   (257, 5, 4), (1000, 3, 16), (4096, 7, 4), (4096, 30, 4), (2048, 59, 8), (9000, 2, 4), (20000, 7, 4)])
 def test_vae_fused_matches_layerwise(B, N, g):
     """The fused four-launch step against the one-launch-per-layer path on the
     same device and inputs: ragged batch sizes, one car per lane, lanes longer
