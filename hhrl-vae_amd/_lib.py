@@ -94,6 +94,7 @@ SIGNATURES = {
     "hhrl_lstm_forward_group": (_I, [_P, _I, _I, _I, _I, _P]),
     "hhrl_lstm_backward_group": (_I, [_P, _I, _I, _I, _I, _P]),
     "hhrl_adam_step": (_I, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _I, _D, _P]),
+    "hhrl_adam_step_copy": (_I, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _I, _D, _P, _P, _P]),
     "hhrl_adam_stage": (_I, [_P, _D, _D, _D, _D, _I, _D, _P]),
     "hhrl_adam_step_dev": (_I, [_P, _P, _P, _P, _L, _P, _P]),
     "hhrl_polyak_update": (_I, [_P, _P, _L, _D, _P]),

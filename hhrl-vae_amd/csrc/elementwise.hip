@@ -95,7 +95,11 @@ __global__ __launch_bounds__(256) void twin_mse_kernel(const float* __restrict__
 
 // ---------------------------------------------------------- optimiser
 // One coalesced pass: reads p,g,m,v (16 B each), writes p,m,v: 28 B / parameter.
-__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* __restrict__ g, float* m, float* v, long n, AdamK k) {
+// copy_dst (optional): one float copied from copy_src by the first thread, for a value that travels behind
+// the gradient (the all-reduced loss of a data-parallel step)
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* __restrict__ g, float* m, float* v, long n, AdamK k,
+                                                   const float* copy_src, float* copy_dst) {
+  if (copy_dst != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *copy_dst = *copy_src;
   const long n4 = n >> 2;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -116,7 +120,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* __rest
   if (i < n) adam_one(p[i], g[i], m[i], v[i], k);
 }
 
-__global__ __launch_bounds__(256) void adam_scalar_kernel(float* p, const float* __restrict__ g, float* m, float* v, long n, AdamK k) {
+__global__ __launch_bounds__(256) void adam_scalar_kernel(float* p, const float* __restrict__ g, float* m, float* v, long n, AdamK k,
+                                                          const float* copy_src, float* copy_dst) {
+  if (copy_dst != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *copy_dst = *copy_src;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) adam_one(p[i], g[i], m[i], v[i], k);
 }
@@ -246,19 +252,30 @@ int hhrl_twin_mse(const float* q1, const float* q2, const float* y, float inv_n,
   return launch_status("twin_mse_kernel");
 }
 
-int hhrl_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
-                   double eps, int step, double grad_scale, void* stream) {
+static int adam_launch(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2, double eps,
+                       int step, double grad_scale, const float* copy_src, float* copy_dst, void* stream) {
   HHRL_REQUIRE(p && g && m && v, "adam_step: null pointer");
   HHRL_REQUIRE(n > 0 && step >= 1, "adam_step: n=%ld step=%d", n, step);
   const AdamK k = make_adam_k(lr, beta1, beta2, eps, step, grad_scale);
   hipStream_t st = as_stream(stream);
   ProfScope ps("adam_kernel", st, 0.0, 28.0 * n);
   if (aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v)) {
-    hipLaunchKernelGGL(adam_kernel, dim3(stream_grid((n + 3) / 4)), dim3(256), 0, st, p, g, m, v, n, k);
+    hipLaunchKernelGGL(adam_kernel, dim3(stream_grid((n + 3) / 4)), dim3(256), 0, st, p, g, m, v, n, k, copy_src, copy_dst);
   } else {
-    hipLaunchKernelGGL(adam_scalar_kernel, dim3(stream_grid(n)), dim3(256), 0, st, p, g, m, v, n, k);
+    hipLaunchKernelGGL(adam_scalar_kernel, dim3(stream_grid(n)), dim3(256), 0, st, p, g, m, v, n, k, copy_src, copy_dst);
   }
   return launch_status("adam_kernel");
+}
+
+int hhrl_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
+                   double eps, int step, double grad_scale, void* stream) {
+  return adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, step, grad_scale, nullptr, nullptr, stream);
+}
+
+int hhrl_adam_step_copy(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
+                        double eps, int step, double grad_scale, const float* copy_src, float* copy_dst, void* stream) {
+  HHRL_REQUIRE(copy_src && copy_dst, "adam_step_copy: null pointer");
+  return adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, step, grad_scale, copy_src, copy_dst, stream);
 }
 
 int hhrl_adam_stage(float* hyper_dev, double lr, double beta1, double beta2, double eps, int step, double grad_scale,

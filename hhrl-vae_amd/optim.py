@@ -7,6 +7,7 @@ import math
 from typing import Dict
 
 import torch
+from typing import Optional
 
 from . import _lib
 from .flat import FlatBuffer, Layout
@@ -64,11 +65,18 @@ class FlatAdam:
     def zero_grad(self) -> None:
         self.g.data.zero_()
 
-    def step(self, grad_scale: float = 1.0) -> None:
+    def step(self, grad_scale: float = 1.0, copy: Optional[tuple] = None) -> None:
+        """copy = (src_ptr, dst_ptr): the launch also copies one float (a loss that travelled behind the gradient)."""
         self.step_count += 1
-        _lib.check(self._lib.hhrl_adam_step(
-            self.p.base_ptr, self.g.base_ptr, self.m.base_ptr, self.v.base_ptr, self.p.layout.size,
-            self.lr, self.beta1, self.beta2, self.eps, self.step_count, float(grad_scale), _lib.stream_ptr()))
+        if copy is None:
+            _lib.check(self._lib.hhrl_adam_step(
+                self.p.base_ptr, self.g.base_ptr, self.m.base_ptr, self.v.base_ptr, self.p.layout.size,
+                self.lr, self.beta1, self.beta2, self.eps, self.step_count, float(grad_scale), _lib.stream_ptr()))
+        else:
+            _lib.check(self._lib.hhrl_adam_step_copy(
+                self.p.base_ptr, self.g.base_ptr, self.m.base_ptr, self.v.base_ptr, self.p.layout.size,
+                self.lr, self.beta1, self.beta2, self.eps, self.step_count, float(grad_scale), copy[0], copy[1],
+                _lib.stream_ptr()))
 
     # -- torch-format round trip ------------------------------------------
     def state_dict(self) -> dict:

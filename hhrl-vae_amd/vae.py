@@ -287,13 +287,13 @@ class Encoder:
             if self.fused:
                 loss = self.loss_and_grads(x, eps, recon_count=global_count, _loss_to_tail=True)
                 hdist.allreduce_sum_(g.full, self.group)                # one flat bucket: gradient + loss, SUM
-                self._loss.copy_(g.full[self.layout.size:self.layout.size + 1])
                 loss = self._loss[0]
+                self.opt.step(copy=(g.tail_ptr, self._loss.data_ptr()))  # :106, and the summed loss into its slot
             else:
                 loss = self.loss_and_grads(x, eps, recon_count=global_count)
                 hdist.allreduce_sum_(g.data, self.group)
                 loss = hdist.allreduce_sum_(loss.clone(), self.group)
-            self.opt.step()                                             # :106
+                self.opt.step()                                         # :106
         return float(loss.item()) if sync else loss
 
     # ------------------------------------------------------------ inference

@@ -261,6 +261,13 @@ int hhrl_lstm_backward_group(const hhrl_lstm_desc* descs, int n, int B, int T, i
  * host, as torch forms them, and only then rounded to fp32 kernel scalars. */
 int hhrl_adam_step(float* p, const float* g, float* m, float* v, long n, double lr,
                    double beta1, double beta2, double eps, int step, double grad_scale, void* stream);
+/* The same launch also copies one float, *copy_dst = *copy_src: the data-parallel form of
+ * Encoder.learn (algorithm.py:92-107) all-reduces the loss in a tail behind the flat gradient, and this
+ * call hands it to the caller's loss slot together with optimizer.step() (:106) instead of a launch of
+ * its own. */
+int hhrl_adam_step_copy(float* p, const float* g, float* m, float* v, long n, double lr,
+                        double beta1, double beta2, double eps, int step, double grad_scale,
+                        const float* copy_src, float* copy_dst, void* stream);
 /* The same update for use inside a captured HIP graph: the eight kernel scalars
  * (step size with bias correction, betas, 1-betas, sqrt(bias correction 2), eps,
  * gradient scale) live in DEVICE memory, 8 floats at hyper_dev.
