@@ -108,6 +108,21 @@ def agent_update_rates(device, steps: int) -> dict:
         dt = time.perf_counter() - t0
         out[name] = {"minibatches_per_s": steps / dt, "ms_per_update": 1e3 * dt / steps,
                      "rows_per_s": steps * net.batch_size / dt}
+        # one policy evaluation as the agents call it every control step (host round trip included)
+        fam = net.fam
+        o = rows[0, :fam.streams[0].width]
+        if fam.goal_dim:
+            act = lambda: net.choose_action(o, rows[1, :fam.goal_dim])
+        elif hasattr(net, "choose_time_action"):
+            act = lambda: net.choose_time_action(o)
+        else:
+            act = lambda: net.choose_action(o)
+        for _ in range(10):
+            act()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            act()
+        out[name]["choose_action_us"] = 1e4 * (time.perf_counter() - t0)
     return out
 
 

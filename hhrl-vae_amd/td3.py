@@ -373,7 +373,7 @@ class TD3Learner:
     """
 
     def __init__(self, fam: Family, device: Optional[str] = None, seed: Optional[int] = None, group=None,
-                 use_graph="auto"):
+                 use_graph=True):
         if not torch.cuda.is_available():
             raise RuntimeError("hhrl_vae_amd needs an AMD GPU (no CPU fallback)")
         self._lib = _lib.load()
@@ -407,7 +407,7 @@ class TD3Learner:
         self._np_rng = np.random.default_rng(3407 if seed is None else seed)     # smoothing noise (algorithm.py:295, 1330)
         self._loss = ops.dev_zeros(2, device=dev)
         self._statics: Dict[int, "TD3Learner._Static"] = {}
-        self._policy_io: Dict[Tuple[int, int], tuple] = {}
+        self._policy_io: Dict[Tuple[int, int], dict] = {}
         self._graphs: Dict[tuple, "torch.cuda.CUDAGraph"] = {}
         self._seen: Dict[tuple, int] = {}
         if use_graph not in (True, False, "auto"):
@@ -564,13 +564,12 @@ class TD3Learner:
     def _run_body(self, key, st, B: int, policy: bool, order: Sequence[int]) -> None:
         """Enqueues the update's kernels eagerly or as a captured HIP graph.
 
-        use_graph=False: always eager.  True: captured after two eager runs of a key, replayed from then on.
-        "auto" (default): the third and fourth runs of a key are timed eagerly, the graph is captured and
-        its first two replays are timed the same way (a device synchronisation on either side, six
-        updates per key in total), and the form with the shorter enqueue-to-finished time of ONE update
-        is kept: what a control loop that calls learn() between environment steps waits for.  Measured:
-        WorkerTD3 at batch 64 0.16 ms eager against 0.10 ms replayed; HATD3Triple (130 launches) within
-        2 % of each other, the graph kept."""
+        use_graph=True (default): captured after two eager runs of a key, replayed from then on.  False:
+        always eager.  "auto": the third and fourth runs of a key are timed eagerly, the graph is captured
+        and its first two replays are timed the same way (a device synchronisation on either side), and
+        the form with the shorter enqueue-to-finished time of ONE update is kept.  Back-to-back updates
+        favour the graph more than that single-update latency shows (HATD3Triple: 0.68 ms replayed against
+        0.76 ms eager in a loop, equal within noise when timed one at a time), hence the default."""
         graph = self._graphs.get(key)
         mode = self.use_graph if self.group is None else False
         tune = self._tune.get(key) if mode == "auto" else None
@@ -736,27 +735,46 @@ class TD3Learner:
         return self._policy_batch(k, o, goal)[0]
 
     def _policy_batch(self, k: int, obs, goal=None) -> np.ndarray:
-        """Actor k on n observations (and goals): one pinned block up, one launch chain, one block down."""
+        """Actor k on n observations (and goals): one pinned block up, one launch chain, one pinned block down.
+        An actor with an LSTM is a chain of T + 5 launches: after two eager calls for a given n it is
+        captured into a HIP graph and replayed (unless use_graph=False)."""
         fam, s = self.fam, self.fam.streams[k]
         o = np.asarray(obs, dtype=np.float32).reshape(-1, s.width)
         n, gd, a = int(o.shape[0]), fam.goal_dim, fam.a_dims[k]
-        io = self._policy_io.get((k, n))
+        key = (k, n)
+        io = self._policy_io.get(key)
         if io is None:
             if len(self._policy_io) > 32:
                 self._policy_io.clear()
             wid = s.width + gd
-            io = self._policy_io[(k, n)] = (torch.zeros(n, wid, dtype=torch.float32).pin_memory(),
-                                            ops.dev_empty(n, wid, device=self.device),
-                                            ops.dev_empty(n, a, device=self.device))
-        h_in, d_in, d_out = io
+            io = self._policy_io[key] = {"h_in": torch.zeros(n, wid, dtype=torch.float32).pin_memory(),
+                                         "d_in": ops.dev_empty(n, wid, device=self.device),
+                                         "d_out": ops.dev_empty(n, a, device=self.device),
+                                         "h_out": torch.zeros(n, a, dtype=torch.float32).pin_memory(),
+                                         "calls": 0, "graph": None}
+        h_in, d_in, d_out, h_out = io["h_in"], io["d_in"], io["d_out"], io["h_out"]
         wid = s.width + gd
         hv = h_in.numpy()
         hv[:, :s.width] = o
         if gd:
             hv[:, s.width:] = np.asarray(goal, dtype=np.float32).reshape(n, gd)
         d_in.copy_(h_in, non_blocking=True)
-        self.actors[k].forward(n, P(d_in), wid, P(d_in, s.width) if gd else None, wid, P(d_out), a)
-        return d_out.cpu().numpy()          # synchronises: the pinned block is free again afterwards
+        run = lambda: self.actors[k].forward(n, P(d_in), wid, P(d_in, s.width) if gd else None, wid, P(d_out), a)
+        if io["graph"] is not None:
+            io["graph"].replay()
+        elif self.use_graph and self.actors[k].lstm is not None and io["calls"] >= 2:
+            graph = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph):
+                run()
+            io["graph"] = graph
+            graph.replay()
+        else:
+            io["calls"] += 1
+            run()
+        h_out.copy_(d_out, non_blocking=True)
+        torch.cuda.current_stream().synchronize()        # the pinned blocks are free again afterwards
+        return h_out.numpy().copy()
 
     # ---- checkpoints ------------------------------------------------------
     def state_dicts(self) -> Dict[str, Dict[str, torch.Tensor]]:
