@@ -1053,16 +1053,73 @@ __global__ __launch_bounds__(256, 1) void vae_decode_kernel(DecArgs g) {
   }
 }
 
+// ------------------------------------------------------------------ slab sums
+// Column `col` of the per-workgroup gradient slabs, rows q, q+4, q+8, ... of n, in a fixed order: eight
+// independent running sums keep eight slab rows in flight per thread.
+__device__ __forceinline__ float slab_quarter_sum(const float* __restrict__ col, long total, int n, int q) {
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
+  int k = q;
+  for (; k + 28 < n; k += 32) {
+    const float v0 = col[(long)k * total], v1 = col[(long)(k + 4) * total], v2 = col[(long)(k + 8) * total],
+                v3 = col[(long)(k + 12) * total], v4 = col[(long)(k + 16) * total], v5 = col[(long)(k + 20) * total],
+                v6 = col[(long)(k + 24) * total], v7 = col[(long)(k + 28) * total];
+    s0 += v0; s1 += v1; s2 += v2; s3 += v3; s4 += v4; s5 += v5; s6 += v6; s7 += v7;
+  }
+  for (; k < n; k += 4) s0 += col[(long)k * total];
+  return ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+}
+
+// The gradient of the per-car layers (flat range [lo, hi)) is complete when the per-car kernel ends.  When
+// the per-lane backward kernel leaves CUs idle (one tile per workgroup, fewer than 256 tiles), extra
+// workgroups of THAT launch sum the per-car slabs (and apply Adam to those parameters) beside it, and the
+// reduction kernel at the end of the step only has the per-lane layers left.
+struct CarReduce {
+  const float* slab;
+  long total, lo, hi;
+  float *grads, *params, *m, *v;      // params == nullptr: gradients only
+  AdamK k;
+  int n_car, first_block, n_blocks;   // workgroups first_block .. first_block + n_blocks - 1 do this work; n_blocks 0: off
+};
+
+// 512 threads: two groups of 64 columns, four waves (slab quarters) each; `red` = 512 floats of LDS
+__device__ __forceinline__ void car_reduce_block(const CarReduce& R, int blk, int tid, float* red) {
+  const int group = tid >> 8, q = (tid >> 6) & 3, p = tid & 63;
+  const long ngroups = (R.hi - R.lo + 63) / 64;
+  for (long base = 2L * blk; base < ngroups; base += 2L * R.n_blocks) {
+    const long i = R.lo + (base + group) * 64 + p;
+    const bool live = i < R.hi;
+    red[(group * 4 + q) * 64 + p] = live ? slab_quarter_sum(R.slab + i, R.total, R.n_car, q) : 0.f;
+    __syncthreads();
+    if (q == 0 && live) {
+      const float* rg = red + group * 256;
+      const float gi = (rg[p] + rg[64 + p]) + (rg[128 + p] + rg[192 + p]);
+      R.grads[i] = gi;
+      if (R.params != nullptr) {
+        float pi = R.params[i], mi = R.m[i], vi = R.v[i];
+        adam_one(pi, gi, mi, vi, R.k);
+        R.params[i] = pi;
+        R.m[i] = mi;
+        R.v[i] = vi;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------ backward
 // SINGLE: the grid covers every tile (one tile per workgroup, the case up to 8192 traffic lanes); a layer's
 // slab entries are then written right after the phase that completes them, under the later phases.
 // NT = 256, or 512 (with SINGLE only: the multi-tile form needs the full register file per wave): four more
 // waves share the copies into LDS and the element-wise phases; the matrix phases stay on waves 0..3.
 template <bool SINGLE, int NT>
-__global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g) {
+__global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, CarReduce cr) {
   static_assert(NT == 256 || (NT == 512 && SINGLE), "helper waves only in the one-tile-per-workgroup form");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (NT == 512 && cr.n_blocks > 0 && (int)blockIdx.x >= cr.first_block) {      // whole workgroups: no barrier is split
+    car_reduce_block(cr, blockIdx.x - cr.first_block, tid, lds);
+    return;
+  }
   const int r = lane & 31, h = lane >> 5;
   const int rb = wave & 1, cb = wave >> 1;
   const int gd = g.g;
@@ -1413,28 +1470,19 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g) {
 // A workgroup owns 64 consecutive parameters; its four waves each sum a quarter of the
 // slabs (four independent running sums keep loads in flight), LDS combines the quarters.
 __global__ __launch_bounds__(256) void vae_reduce_grads_kernel(const float* __restrict__ slab, long total, int n_car, int n_lane,
-                                                               long car_lo, long car_hi, float* grads,
+                                                               long car_lo, long car_hi, long skip_lo, long skip_hi, float* grads,
                                                                const float* __restrict__ loss_part, const float* __restrict__ kl_part,
                                                                float* loss, float* params, float* m, float* v, AdamK k) {
   __shared__ float red[4][64];
   const int p = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const long i = (long)blockIdx.x * 64 + p;
+  const long i0 = (long)blockIdx.x * 64;
+  if (i0 >= skip_lo && i0 < skip_hi) return;           // columns already summed beside the per-lane backward kernel
+  const long i = i0 + p;
   float s = 0.f;
   if (i < total) {
     // per-car layers (loc, func.*) occupy [car_lo, car_hi) and come from the per-car kernel's slabs
     const int n = (i >= car_lo && i < car_hi) ? n_car : n_lane;
-    const float* col = slab + i;
-    // eight independent running sums: eight slab rows in flight per thread
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
-    int k = q;
-    for (; k + 28 < n; k += 32) {
-      const float v0 = col[(long)k * total], v1 = col[(long)(k + 4) * total], v2 = col[(long)(k + 8) * total],
-                  v3 = col[(long)(k + 12) * total], v4 = col[(long)(k + 16) * total], v5 = col[(long)(k + 20) * total],
-                  v6 = col[(long)(k + 24) * total], v7 = col[(long)(k + 28) * total];
-      s0 += v0; s1 += v1; s2 += v2; s3 += v3; s4 += v4; s5 += v5; s6 += v6; s7 += v7;
-    }
-    for (; k < n; k += 4) s0 += col[(long)k * total];
-    s = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+    s = slab_quarter_sum(slab + i, total, n, q);
   }
   red[q][p] = s;
   __syncthreads();
@@ -1605,22 +1653,33 @@ static int vae_step_impl(float* params, float* grads, float* m, float* v, const 
     hipLaunchKernelGGL(vae_car_fwd_bwd_kernel, dim3(ncar), dim3(256), CAR_LDS_FLOATS * 4, st, ca);
     HHRL_TRY(launch_status("vae_car_fwd_bwd_kernel"));
   }
+  // per-car gradient slabs summed by extra workgroups of the per-lane backward launch, on CUs it leaves idle
+  CarReduce cr;
+  cr.slab = w.slab; cr.total = n_flat; cr.lo = car_lo; cr.hi = car_hi;
+  cr.grads = grads; cr.params = adam ? params : nullptr; cr.m = m; cr.v = v;
+  cr.k = adam ? *adam : AdamK();
+  cr.n_car = ncar; cr.first_block = nlane; cr.n_blocks = 0;
+  if (nlane >= la.tiles && lane_threads == 512 && nlane < 256 && car_lo % 64 == 0) {
+    const long pairs = ((car_hi - car_lo + 63) / 64 + 1) / 2;
+    cr.n_blocks = (int)(pairs < 256 - nlane ? pairs : 256 - nlane);
+  }
+  const long skip_lo = cr.n_blocks > 0 ? car_lo : 0, skip_hi = cr.n_blocks > 0 ? ((car_hi + 63) / 64) * 64 : 0;
   {
     ProfScope ps("vae_lane_backward_kernel", st, 4.0 * lane_macs * B, 4.0 * B * (2.0 * N + g + 32));
     if (nlane >= la.tiles && lane_threads == 512)
-      hipLaunchKernelGGL((vae_lane_backward_kernel<true, 512>), dim3(nlane), dim3(512), LN_LDS_FLOATS * 4, st, la);
+      hipLaunchKernelGGL((vae_lane_backward_kernel<true, 512>), dim3(nlane + cr.n_blocks), dim3(512), LN_LDS_FLOATS * 4, st, la, cr);
     else if (nlane >= la.tiles)
-      hipLaunchKernelGGL((vae_lane_backward_kernel<true, 256>), dim3(nlane), dim3(256), LN_LDS_FLOATS * 4, st, la);
+      hipLaunchKernelGGL((vae_lane_backward_kernel<true, 256>), dim3(nlane), dim3(256), LN_LDS_FLOATS * 4, st, la, cr);
     else
-      hipLaunchKernelGGL((vae_lane_backward_kernel<false, 256>), dim3(nlane), dim3(256), LN_LDS_FLOATS * 4, st, la);
+      hipLaunchKernelGGL((vae_lane_backward_kernel<false, 256>), dim3(nlane), dim3(256), LN_LDS_FLOATS * 4, st, la, cr);
     HHRL_TRY(launch_status("vae_lane_backward_kernel"));
   }
   {
     // reads every slab column once (per-car columns from ncar slabs, the others from nlane), writes the gradient
-    const double slab_floats = (double)(car_hi - car_lo) * ncar + (double)(n_flat - (car_hi - car_lo)) * nlane;
+    const double slab_floats = (cr.n_blocks > 0 ? 0.0 : (double)(car_hi - car_lo) * ncar) + (double)(n_flat - (car_hi - car_lo)) * nlane;
     ProfScope ps("vae_reduce_grads_kernel", st, 0.0, 4.0 * (slab_floats + n_flat * (adam ? 7.0 : 1.0)));
     hipLaunchKernelGGL(vae_reduce_grads_kernel, dim3(ceil_div(n_flat, 64)), dim3(256), 0, st, w.slab, n_flat, ncar, nlane,
-                       car_lo, car_hi, grads, w.loss_part, w.kl_part, loss, adam ? params : nullptr, m, v,
+                       car_lo, car_hi, skip_lo, skip_hi, grads, w.loss_part, w.kl_part, loss, adam ? params : nullptr, m, v,
                        adam ? *adam : AdamK());
     HHRL_TRY(launch_status("vae_reduce_grads_kernel"));
   }
