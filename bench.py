@@ -156,8 +156,12 @@ def pmc_traffic(workload: str, kernel: str):
     of this workload (rocprofv3 FETCH_SIZE / WRITE_SIZE passes, read bytes
     doubled as gfx950 requires); None when no summary covers the workload."""
     import glob
+    import re
+
+    def order(path):                       # r01_v8 before r01_v11: numbers compare as numbers
+        return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(path))]
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), key=order):
         try:
             with open(path) as f:
                 d = json.load(f)
