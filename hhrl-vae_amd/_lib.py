@@ -76,6 +76,7 @@ SIGNATURES = {
     "hhrl_broadcast_rows": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     "hhrl_copy2d": (_I, [_P, _I, _P, _I, _I, _I, _P]),
     "hhrl_copy2d_group": (_I, [_P, _I, _I, _P]),
+    "hhrl_gather_rows": (_I, [_P, _L, _I, _P, _P, _I, _I, _I, _P]),
     "hhrl_fill": (_I, [_P, _L, _F, _P]),
     "hhrl_vae_reparam": (_I, [_P, _P, _P, _I, _I, _P]),
     "hhrl_vae_elbo": (_I, [_P, _P, _P, _F, _P, _P, _I, _I, _I, _P]),

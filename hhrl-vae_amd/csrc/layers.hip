@@ -124,6 +124,17 @@ __global__ void copy2d_kernel(const float* __restrict__ in, int ldi, float* out,
   out[r * ldo + c] = in[r * ldi + c];
 }
 
+// out[r][0..C) = in[idx[r]][0..C): the rows of a sampled minibatch out of a device-resident replay buffer
+__global__ void gather_rows_kernel(const float* __restrict__ in, long ldi, const int* __restrict__ idx, int n_in, float* out,
+                                   int ldo, int M, int C) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)M * C) return;
+  const int c = e % C;
+  const long r = e / C;
+  const int src = min(max(idx[r], 0), n_in - 1);          // an index outside the buffer cannot leave it
+  out[r * ldo + c] = in[(long)src * ldi + c];
+}
+
 struct CopyInst { const float* in; float* out; int ldi, ldo, C; };
 struct CopyGroup { CopyInst in[HHRL_COPY_GROUP_MAX]; };
 __global__ void copy2d_group_kernel(CopyGroup grp, int M) {
@@ -292,6 +303,14 @@ int hhrl_copy2d(const float* in, int ldi, float* out, int ldo, int M, int C, voi
   ProfScope ps("copy2d_kernel", as_stream(stream), 0.0, 8.0 * M * C);
   hipLaunchKernelGGL(copy2d_kernel, dim3(ceil_div((long)M * C, 256)), dim3(256), 0, as_stream(stream), in, ldi, out, ldo, M, C);
   return launch_status("copy2d_kernel");
+}
+
+int hhrl_gather_rows(const float* in, long ldi, int n_in, const int* idx, float* out, int ldo, int M, int C, void* stream) {
+  HHRL_REQUIRE(in && idx && out, "gather_rows: null pointer");
+  HHRL_REQUIRE(M > 0 && C > 0 && n_in > 0 && ldi >= C && ldo >= C, "gather_rows: bad shape M=%d C=%d n_in=%d ldi=%ld ldo=%d", M, C, n_in, ldi, ldo);
+  ProfScope ps("gather_rows_kernel", as_stream(stream), 0.0, 8.0 * M * C);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(ceil_div((long)M * C, 256)), dim3(256), 0, as_stream(stream), in, ldi, idx, n_in, out, ldo, M, C);
+  return launch_status("gather_rows_kernel");
 }
 
 int hhrl_copy2d_group(const hhrl_copy_desc* d, int n, int M, void* stream) {

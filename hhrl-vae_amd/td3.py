@@ -373,7 +373,7 @@ class TD3Learner:
     """
 
     def __init__(self, fam: Family, device: Optional[str] = None, seed: Optional[int] = None, group=None,
-                 use_graph=True):
+                 use_graph=True, device_replay: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError("hhrl_vae_amd needs an AMD GPU (no CPU fallback)")
         self._lib = _lib.load()
@@ -413,6 +413,10 @@ class TD3Learner:
         if use_graph not in (True, False, "auto"):
             raise ValueError("use_graph must be True, False or 'auto'")
         self.use_graph = use_graph
+        # device_replay: the flat replay buffer is mirrored in device memory (new rows are uploaded before an
+        # update) and a minibatch is gathered there from the sampled row numbers, instead of being gathered
+        # on the host and uploaded whole.  Classes with a flat `memory` array only, single device only.
+        self.device_replay = bool(device_replay) and group is None
         self._tune: Dict[tuple, dict] = {}
         # column offsets inside a replay row
         f = fam
@@ -460,13 +464,17 @@ class TD3Learner:
             for _ in range(n_opt):
                 self.hyper_off.append(off)
                 off += 64
+            self.idx_off = off                 # B int32 row numbers of a device-resident replay buffer
+            off += a64(B)
             self.total = off
             self.d_in = ops.dev_zeros(off, device=dev)
             self.rows = self.d_in[:self.n_rows].view(B, W)
             self.noise = [self.d_in[o:o + B * a].view(B, a) for o, a in zip(self.noise_off, fam.a_dims)]
             self.hyper = [self.d_in[o:o + 8] for o in self.hyper_off]
+            self.idx = self.d_in[self.idx_off:self.idx_off + B].view(torch.int32)
             self.h_in = [torch.zeros(off, dtype=torch.float32).pin_memory() for _ in range(self.RING)]
             self.h_np = [t.numpy() for t in self.h_in]
+            self.h_idx = [t[self.idx_off:self.idx_off + B].view(torch.int32).numpy() for t in self.h_in]
             self.events: List[Optional["torch.cuda.Event"]] = [None] * self.RING
             self.turn = 0
             self.pi = [ops.dev_empty(B, a, device=dev) for a in fam.a_dims]
@@ -479,17 +487,27 @@ class TD3Learner:
                 self.events[slot].synchronize()
             return slot
 
-    def learn_rows(self, rows, noise: Optional[Sequence] = None, order: Optional[Sequence[int]] = None) -> None:
+    def learn_rows(self, rows, noise: Optional[Sequence] = None, order: Optional[Sequence[int]] = None,
+                   _indices=None) -> None:
         """One TD3 update on a [B, row_width] block of replay rows (numpy array, host or device tensor).
+        _indices (device replay, rows=None): the B row numbers to gather from the device mirror instead.
 
         The kernel sequence of an update depends only on (B, policy step?, actor order); after two
         eager runs of a given combination it is captured into a HIP graph and replayed.  What changes
         from update to update (rows, noise, the scalars of the Adam steps) reaches the device in one
         transfer before the replay."""
         fam = self.fam
-        B, W = int(rows.shape[0]), fam.row_width
-        if rows.ndim != 2 or rows.shape[1] != W or B == 0:
-            raise ValueError("rows must be [B, %d], got %s" % (W, tuple(rows.shape)))
+        W = fam.row_width
+        gather = _indices is not None
+        if gather:
+            _indices = np.asarray(_indices)
+            B = int(_indices.shape[0])
+            if _indices.ndim != 1 or B == 0:
+                raise ValueError("indices must be a non-empty vector")
+        else:
+            B = int(rows.shape[0])
+            if rows.ndim != 2 or rows.shape[1] != W or B == 0:
+                raise ValueError("rows must be [B, %d], got %s" % (W, tuple(rows.shape)))
         st = self._statics.get(B)
         if st is None:
             st = self._statics[B] = TD3Learner._Static(fam, B, self.device, 1 + len(self.actors))
@@ -507,8 +525,10 @@ class TD3Learner:
         # ---- one pinned block: rows | noise | scalars of the Adam steps this update will take
         slot = st.next_slot()
         h = st.h_np[slot]
-        rows_on_device = isinstance(rows, torch.Tensor) and rows.is_cuda
-        if not rows_on_device:
+        rows_on_device = gather or (isinstance(rows, torch.Tensor) and rows.is_cuda)
+        if gather:
+            st.h_idx[slot][:] = _indices
+        elif not rows_on_device:
             h[:st.n_rows].reshape(B, W)[:] = rows.numpy() if isinstance(rows, torch.Tensor) else rows
         for k, (o, a) in enumerate(zip(st.noise_off, fam.a_dims)):
             dst = h[o:o + B * a].reshape(B, a)
@@ -524,14 +544,16 @@ class TD3Learner:
             for j, a in enumerate(self.actors):
                 h[st.hyper_off[1 + j]:st.hyper_off[1 + j] + 8] = a.opt.next_step_scalars()
         if rows_on_device:
-            st.rows.copy_(rows)
+            if not gather:
+                st.rows.copy_(rows)
             st.d_in[st.n_rows:].copy_(st.h_in[slot][st.n_rows:], non_blocking=True)
         else:
             st.d_in.copy_(st.h_in[slot], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         st.events[slot] = ev
-        key = (B, policy, order)
+        st.gather = gather                                  # the update starts by gathering its rows on the device
+        key = (B, policy, order, gather)
         self._run_body(key, st, B, policy, order)
         # host-side bookkeeping of what was just enqueued
         self.critic.opt.commit_step()
@@ -610,6 +632,8 @@ class TD3Learner:
         fam, lib, sp = self.fam, self._lib, _lib.stream_ptr()
         W = fam.row_width
         rows, noise, pi, y = st.rows, st.noise, st.pi, st.y
+        if getattr(st, "gather", False):
+            check(lib.hhrl_gather_rows(P(self._dev_mem), W, self.memory_capacity, st.idx.data_ptr(), P(rows), W, B, W, sp))
         inv_n = 1.0 / float(B * self.world_size)
         R = lambda col: P(rows, col)
         goal = R(self.col_goal) if fam.goal_dim else None
@@ -723,7 +747,11 @@ class TD3Learner:
     def _learn(self, indices=None, noise=None, order=None) -> None:
         if indices is None:
             indices = np.random.choice(min(self._n_stored(), self.memory_capacity), size=self.batch_size)
-        self.learn_rows(self._sample_rows(np.asarray(indices)), noise, order)
+        if self.device_replay and hasattr(self, "_sync_replay"):
+            self._sync_replay()
+            self.learn_rows(None, noise, order, _indices=np.asarray(indices))
+        else:
+            self.learn_rows(self._sample_rows(np.asarray(indices)), noise, order)
 
     # ---- inference --------------------------------------------------------
     def _act(self, k: int, obs, goal=None) -> np.ndarray:
@@ -823,6 +851,41 @@ class _FlatReplayMixin:
     def _init_memory(self):
         self.memory = np.zeros((self.memory_capacity, self.fam.row_width))
         self.pointer = 0
+        if self.device_replay:
+            self._dev_mem = ops.dev_zeros(self.memory_capacity, self.fam.row_width, device=self.device)
+            self._synced = 0                         # value of `pointer` up to which the mirror is current
+            n_stage = min(self.memory_capacity, 4096)
+            self._stage = torch.zeros(n_stage, self.fam.row_width, dtype=torch.float32).pin_memory()
+            self._stage_np = self._stage.numpy()
+            self._stage_ev = None
+
+    def mark_replay_dirty(self) -> None:
+        """Call after writing `memory` rows directly that were already mirrored (store_transition and
+        writes followed by a larger `pointer` are picked up without it): the whole buffer is uploaded again."""
+        if self.device_replay:
+            self._synced = self.pointer - self.memory_capacity
+
+    def _sync_replay(self) -> None:
+        """Uploads the rows stored since the last update into the device mirror (fp32), oldest first."""
+        cap = self.memory_capacity
+        new = min(self.pointer - self._synced, cap)
+        if new <= 0:
+            return
+        lo = (self.pointer - new) % cap
+        spans = [(lo, min(lo + new, cap))]
+        if lo + new > cap:
+            spans.append((0, lo + new - cap))
+        n_stage = self._stage.shape[0]
+        for a, b in spans:
+            for c in range(a, b, n_stage):
+                n = min(n_stage, b - c)
+                if self._stage_ev is not None:
+                    self._stage_ev.synchronize()            # the previous transfer has read the staging block
+                self._stage_np[:n] = self.memory[c:c + n]
+                self._dev_mem[c:c + n].copy_(self._stage[:n], non_blocking=True)
+                self._stage_ev = torch.cuda.Event()
+                self._stage_ev.record()
+        self._synced = self.pointer
 
     def _store(self, *parts) -> None:
         transition = np.hstack(parts)

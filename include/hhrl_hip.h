@@ -101,6 +101,11 @@ int hhrl_copy2d(const float* in, int ldi, float* out, int ldo, int M, int C, voi
 #define HHRL_COPY_GROUP_MAX 32
 typedef struct { const float* in; int ldi; float* out; int ldo; int C; } hhrl_copy_desc;
 int hhrl_copy2d_group(const hhrl_copy_desc* blocks, int n, int M, void* stream);
+/* out[r][0..C) = in[idx[r]][0..C) for r < M: the minibatch gather `self.memory[indices, :]`
+ * (algorithm.py:287, 483, 772, 1320) when the replay buffer is mirrored in device memory
+ * (in: [n_in][ldi] fp32, idx: M int32 row numbers; numbers outside [0, n_in) are clamped). */
+int hhrl_gather_rows(const float* in, long ldi, int n_in, const int* idx, float* out, int ldo, int M, int C,
+                     void* stream);
 /* p[i] = value */
 int hhrl_fill(float* p, long n, float value, void* stream);
 

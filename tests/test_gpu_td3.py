@@ -182,6 +182,52 @@ def test_td3_manager_off_policy_correction():
     close_dict("exp_avg_sq/critic", net.critic.opt.v.state_dict(), sub(fx, "learn/final/exp_avg_sq/critic"), False, atol_rel=1e-5)
 
 
+def test_td3_device_replay_matches_host_gather():
+    """device_replay=True (replay rows mirrored in device memory, minibatch gathered there from the sampled
+    row numbers) gives bit-identical updates to the host gather: bulk fill, single stores, ring wrap-around,
+    a direct overwrite announced with mark_replay_dirty()."""
+    import hhrl_vae_amd.algorithm as A
+    for make in ((lambda **kw: A.WorkerTD3(gen.cav_cfg(o=5, g=3, hidden=(16, 12), batch=8, cap=24), seed=5, **kw)),
+                          (lambda **kw: A.HATD3Triple(gen.light_cfg(o=(5, 6, 7), T=4, s=8, a=(1, 2, 3), actor_h=(12, 10),
+                                                                    critic_h=(14, 12), batch=8, cap=24), seed=5, **kw))):
+        host, dev = make(), make(device_replay=True)
+        assert dev.device_replay and not host.device_replay
+        W = host.fam.row_width
+        rs = np.random.RandomState(3)
+        rows = rs.uniform(-1, 1, size=(20, W))
+        for net in (host, dev):
+            net.memory[:20] = rows
+            net.pointer = 20
+        step = [0]
+
+        def both_learn():
+            step[0] += 1
+            idx = np.random.RandomState(100 + step[0]).choice(min(host.pointer, 24), size=8)
+            noise = [np.random.RandomState(200 + step[0] + k).standard_normal((8, a)).astype(np.float32)
+                     for k, a in enumerate(host.fam.a_dims)]
+            order = np.random.RandomState(300 + step[0]).permutation(len(host.fam.a_dims))
+            for net in (host, dev):
+                net._learn(idx, noise, order)
+            a, b = host.state_dicts(), dev.state_dicts()
+            for n in a:
+                for k in a[n]:
+                    assert torch.equal(a[n][k], b[n][k]), (step[0], n, k)
+        for _ in range(4):
+            both_learn()
+        for i in range(9):                                   # single stores, wrapping around the 24-row ring
+            row = rs.uniform(-1, 1, size=W)
+            for net in (host, dev):
+                net._store(row)
+            both_learn()
+        assert host.pointer == 29
+        patch = rs.uniform(-1, 1, size=(3, W))
+        for net in (host, dev):
+            net.memory[10:13] = patch                        # a direct write into rows that are already mirrored
+        dev.mark_replay_dirty()
+        for _ in range(3):
+            both_learn()
+
+
 def test_td3_checkpoint_roundtrip(tmp_path):
     """save/load: the reference's file suffixes and torch formats
     (algorithm.py:1368-1382); a torch Adam accepts the optimizer file."""
