@@ -4,7 +4,8 @@ import numpy as np, torch, gen
 from hhrl_vae_amd.algorithm import HATD3Triple, WorkerTD3
 from hhrl_vae_amd import _lib
 which = sys.argv[1]
-mk = lambda ug: WorkerTD3(gen.cav_cfg(cap=4096), use_graph=ug) if which == 'worker' else HATD3Triple(gen.light_cfg(cap=2048), use_graph=ug)
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 64          # usage: td3_prof.py <worker|triple> [batch]
+mk = lambda ug: WorkerTD3(gen.cav_cfg(cap=4096, batch=batch), use_graph=ug) if which == 'worker' else HATD3Triple(gen.light_cfg(cap=2048, batch=batch), use_graph=ug)
 net = mk(False)
 n = 2048
 net.memory[:n] = np.random.RandomState(1).uniform(0, 1, size=(n, net.fam.row_width)); net.pointer = n
