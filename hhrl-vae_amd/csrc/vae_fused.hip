@@ -313,14 +313,9 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
         const float a = (bk >= 0 && bk - b_first == r) ? 1.f : 0.f;
         P = __builtin_amdgcn_mfma_f32_32x32x2f32(a, half[(k + h) * 33 + r], P, 0, 0, 0);
       }
-      const long left = g.rows - (long)tile * 32;
-      const int b_last = __shfl(in_b, left < 32 ? (int)left - 1 : 31, 64);
-      const int nslots = b_last - b_first + 1;
+      // every tile owns 32 rows of dpart; rows past its last traffic lane are zero and nobody reads them
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int slot = drow(i, h);
-        if (slot < nslots) g.dpart[((long)tile * 32 + slot) * 32 + r] = P[i];
-      }
+      for (int i = 0; i < 16; ++i) g.dpart[((long)tile * 32 + drow(i, h)) * 32 + r] = P[i];
     }
     wave_sync();
     HHRL_STAMP(0, 9);
