@@ -131,15 +131,15 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
       cat[rr * 65 + 32 + r] = b_rr >= 0 ? loc_rr * wl_r + bl_r : 0.f;
     }
   };
-  fetch_tile(blockIdx.x * 4 + wave);
   {
+    // the matrices are requested first (the longest transfer), then the wave's tile; biases and the narrow
+    // layers travel in the same round trip
     float4 v0[8], v2[4];
     request_w4<128, 64>(v0, g.w0, tid);
     request_w4<32, 128>(v2, g.w2, tid);
-    // biases and the narrow layers travel in the same round trip as the matrices
     const float p_b0 = g.b0[tid & 127], p_b2 = g.b2[r], p_w4 = g.w4[r], p_b4 = g.b4[0];
-    build_cat();                         // wave-private, under the weights' round trip
-    commit_w4<128, 64>(W0s, 65, v0, tid);
+    fetch_tile(blockIdx.x * 4 + wave);
+    commit_w4<128, 64>(W0s, 65, v0, tid);   // waits for the matrices only: the tile's loads stay in flight
     commit_w4<32, 128>(W2s, 129, v2, tid);
     if (tid < 128) b0s[tid] = p_b0;
     if (tid < 32) {
@@ -149,6 +149,7 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
       blocs[tid] = bl_r;
     }
     if (tid == 0) b4s[0] = p_b4;
+    build_cat();                         // wave-private image of the wave's first tile
   }
   __syncthreads();
   HHRL_STAMP(0, 1);
