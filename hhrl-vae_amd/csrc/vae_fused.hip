@@ -46,31 +46,43 @@ struct Offsets {
 };
 
 // ===================================================================== per-car kernel
+// func.0 acts on [d2 of the car's traffic lane | loc embedding of the car].  Both parts are affine in
+// something much smaller than a car row: d2 is shared by the cars of a lane, the embedding is
+// loc * wloc + bloc.  With W0 = [A | E] (columns 0..31 and 32..63) the pre-activation of func.0 is
+//     U[lane] + loc * p        U = d2 A^T + b0 + E bloc  (per lane: the forward lane kernel)     p = E wloc
+// and with S[lane] = sum of df1 over the lane's cars, s = sum of loc * df1 and db0 = sum of df1 over all cars
+//     dd2 = S A      dA = S^T d2                          (per lane: the backward lane kernel)
+//     dE = s wloc^T + db0 bloc^T      dwloc = E^T s      dbloc = E^T db0
+// so no product with func.0's matrix is left per car.  The per-car kernel computes f1 element-wise,
+// runs func.2 / func.4 and their backward on the matrix core, and leaves S (one row per (car tile,
+// traffic lane in it), summed on the matrix core with a 0/1 indicator operand), s and db0.
 struct CarArgs {
   const float* data;  // [rows][2]  (loc, v)
-  const float* d2;    // [B][32]
-  const float *wloc, *bloc, *w0, *b0, *w2, *b2, *w4, *b4;
-  float* dpart;       // [tiles * 32][32] gradient at the decoder output, summed per traffic lane within a tile:
-                      // row tile*32 + s belongs to traffic lane (tile*32)/N + s
+  const float* u;     // [B][128]
+  const float* pvec;  // [128]
+  const float *w0, *w2, *b2, *w4, *b4;
+  float* spart;       // [tiles * R][128] sum of df1 per traffic lane within a tile:
+                      // row tile*R + s belongs to traffic lane (tile*32)/N + s
   float* slab;        // [gridDim.x][total]
   float* loss_part;   // [gridDim.x]
   Offsets off;
   long rows;          // B*N
-  int N, tiles;
+  int N, tiles, R;    // R = most traffic lanes a tile of 32 cars can touch
   float recon_scale;
-  int vec4;           // slab rows and the func.0 / func.2 weight offsets are 16-byte aligned
+  int vec4;           // slab rows and the func.2 weight offset are 16-byte aligned
 };
 
-constexpr int CAR_W0 = 0;                         // [128][65]
-constexpr int CAR_W2 = CAR_W0 + 128 * 65;         // [32][129]
-constexpr int CAR_SMALL = CAR_W2 + 32 * 129;      // b0[128] b2[32] w4[32] wloc[32] bloc[32] b4[1]
-constexpr int CAR_WAVE0 = CAR_SMALL + 320;
-constexpr int CAR_CAT = 0;                        // per wave: [32][65]
-constexpr int CAR_HALF = CAR_CAT + 32 * 65;       // [32][65]
-constexpr int CAR_F2 = CAR_HALF + 32 * 65;        // [32][33]
-constexpr int CAR_ROW = CAR_F2 + 32 * 33;         // loc[32] v[32] dpre[32] (+32 spare)
+constexpr int CAR_W2 = 0;                          // [32][129]
+constexpr int CAR_SMALL = CAR_W2 + 32 * 129;       // b2[32] w4[32] b4[1]
+constexpr int CAR_WAVE0 = CAR_SMALL + 96;
+constexpr int CAR_F1 = 0;                          // per wave: [32][129] f1, later df1
+constexpr int CAR_F2 = CAR_F1 + 32 * 129;          // [32][33]
+constexpr int CAR_ROW = CAR_F2 + 32 * 33;          // dpre[32] (+96 spare)
 constexpr int CAR_WAVE_FLOATS = CAR_ROW + 128;
 constexpr int CAR_LDS_FLOATS = CAR_WAVE0 + 4 * CAR_WAVE_FLOATS;
+
+// most traffic lanes that 32 consecutive cars can belong to
+static inline int lanes_per_car_tile(int N) { const int v = 31 / N + 2; return v < 32 ? v : 32; }
 
 __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -78,124 +90,106 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
   const int r = lane & 31, h = lane >> 5;
 
   HHRL_STAMP(0, 0);
-  float* W0s = lds + CAR_W0;
   float* W2s = lds + CAR_W2;
-  float* b0s = lds + CAR_SMALL;
-  float* b2s = b0s + 128;
+  float* b2s = lds + CAR_SMALL;
   float* w4s = b2s + 32;
-  float* wlocs = w4s + 32;
-  float* blocs = wlocs + 32;
-  float* b4s = blocs + 32;
-  // inputs of the wave's first tile are requested before the weights, so both round trips overlap
-  float in_loc, in_v, in_d2[16];
+  float* b4s = w4s + 32;
+  float* wl = lds + CAR_WAVE0 + wave * CAR_WAVE_FLOATS;
+  float* f1i = wl + CAR_F1;
+  float* f2i = wl + CAR_F2;
+  float* dpre = wl + CAR_ROW;
+
+  // Inputs of a tile.  Lane r (both halves) holds car r; for the sixteen rows drow(i, h) of the accumulator
+  // layout a lane also holds their loc, and column 32 t + r of their traffic lane's U row.
+  float in_v, loc_i[16], ind[16];
   int in_b;
+  f32x16 f1[4];                                      // U rows on arrival, f1 after the activation
   auto fetch_tile = [&](int tile) {
     const int row = tile * 32 + r;                                   // the host keeps the car count below 2^31
     const bool valid = tile < g.tiles && row < g.rows;
     const float2 lv = valid ? *reinterpret_cast<const float2*>(g.data + 2 * (long)row) : make_float2(0.f, 0.f);
-    in_loc = lv.x;
-    in_v = lv.y;
     in_b = valid ? (int)((unsigned)row / (unsigned)g.N) : -1;
-    // rows 2*it + h of the d2 block: lane r reads column r of the traffic lane of car 2*it + h.  All
-    // exchanges first, then all loads from clamped addresses (no branch between them), so that the
-    // sixteen round trips overlap.
-    int b_it[16];
+    // all exchanges first, then all loads from clamped addresses (no branch between them), so that the
+    // round trips overlap.  Rows without a car read lane 0's row; their gradients are zero (dpre = 0).
+    int b_i[16];
 #pragma unroll
-    for (int it = 0; it < 16; ++it) b_it[it] = __shfl(in_b, 2 * it + h, 64);
+    for (int i = 0; i < 16; ++i) b_i[i] = __shfl(in_b, drow(i, h), 64);
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      const float dv = g.d2[(long)max(b_it[it], 0) * 32 + r];
-      in_d2[it] = b_it[it] >= 0 ? dv : 0.f;
+    for (int i = 0; i < 16; ++i) {
+      const float* up = g.u + (long)max(b_i[i], 0) * 128 + r;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) f1[t][i] = up[32 * t];
     }
+    // 0/1 operand of the per-lane sums: step k of the product takes car k + h, output row s = lane r
+    const int b_first = __builtin_amdgcn_readfirstlane(in_b);
+#pragma unroll
+    for (int k = 0; k < 32; k += 2) {
+      const int b0 = __builtin_amdgcn_readlane(in_b, k), b1 = __builtin_amdgcn_readlane(in_b, k + 1);
+      const int bk = h ? b1 : b0;
+      ind[k >> 1] = (bk >= 0 && bk - b_first == r) ? 1.f : 0.f;
+    }
+    in_v = lv.y;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) loc_i[i] = __shfl(lv.x, drow(i, h), 64);
   };
-  float* wl = lds + CAR_WAVE0 + wave * CAR_WAVE_FLOATS;
-  float* cat = wl + CAR_CAT;
-  float* half = wl + CAR_HALF;
-  float* f2i = wl + CAR_F2;
-  float* locs = wl + CAR_ROW;
-  float* vs = locs + 32;
-  float* dpre = vs + 32;
-  const float wl_r = g.wloc[r], bl_r = g.bloc[r];
-  // cat image of the fetched tile: [d2 of the car's lane | loc embedding], rows 2*it + h, column r
-  auto build_cat = [&]() {
-    if (h == 0) {
-      locs[r] = in_loc;
-      vs[r] = in_v;
-    }
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      const int rr = 2 * it + h;
-      const float loc_rr = __shfl(in_loc, rr, 64);
-      const int b_rr = __shfl(in_b, rr, 64);
-      cat[rr * 65 + r] = in_d2[it];
-      cat[rr * 65 + 32 + r] = b_rr >= 0 ? loc_rr * wl_r + bl_r : 0.f;
-    }
-  };
+
+  float p_t[4];
+  float w0e[16];                                     // W0[16 og + k][32 + j] for the loc gradients at the end
   {
-    // the matrices are requested first (the longest transfer), then the wave's tile; biases and the narrow
-    // layers travel in the same round trip
-    float4 v0[8], v2[4];
-    request_w4<128, 64>(v0, g.w0, tid);
+    // the matrix is requested first (the longest transfer), then the wave's tile; the narrow layers
+    // travel in the same round trip
+    float4 v2[4];
     request_w4<32, 128>(v2, g.w2, tid);
-    const float p_b0 = g.b0[tid & 127], p_b2 = g.b2[r], p_w4 = g.w4[r], p_b4 = g.b4[0];
+    const float p_b2 = g.b2[r], p_w4 = g.w4[r], p_b4 = g.b4[0];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) p_t[t] = g.pvec[32 * t + r];
     fetch_tile(blockIdx.x * 4 + wave);
-    commit_w4<128, 64>(W0s, 65, v0, tid);   // waits for the matrices only: the tile's loads stay in flight
+    {
+      const int j = tid & 31, og = tid >> 5;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) w0e[k] = g.w0[(16 * og + k) * 64 + 32 + j];
+    }
     commit_w4<32, 128>(W2s, 129, v2, tid);
-    if (tid < 128) b0s[tid] = p_b0;
     if (tid < 32) {
       b2s[tid] = p_b2;
       w4s[tid] = p_w4;
-      wlocs[tid] = wl_r;
-      blocs[tid] = bl_r;
     }
     if (tid == 0) b4s[0] = p_b4;
-    build_cat();                         // wave-private image of the wave's first tile
   }
   __syncthreads();
   HHRL_STAMP(0, 1);
 
-  // weight-gradient accumulators; the first tile starts its products from a zero operand instead of
-  // zero-filling 192 registers that would then be live through its whole forward pass
-  f32x16 dW0[4][2], dW2[4];
-  float db0[4] = {0.f, 0.f, 0.f, 0.f};
-  float w4acc = 0.f, db2acc = 0.f, wlocacc = 0.f, blocacc = 0.f, b4acc = 0.f, lossacc = 0.f;
+  // weight-gradient accumulators of func.2 and the column sums, kept across the wave's tiles
+  f32x16 dW2[4];
+  float db0[4] = {0.f, 0.f, 0.f, 0.f}, sacc[4] = {0.f, 0.f, 0.f, 0.f};
+  float w4acc = 0.f, db2acc = 0.f, b4acc = 0.f, lossacc = 0.f;
 
   auto process_tile = [&](auto first_tag, int tile) {
     constexpr bool FIRST = decltype(first_tag)::value;
-    if (!FIRST) {                                                  // the first tile was prepared in the prologue
-      fetch_tile(tile);
-      build_cat();
-    }
+    if (!FIRST) fetch_tile(tile);                                  // the first tile was requested in the prologue
     const float v = in_v;
     const bool valid = in_b >= 0;
-    wave_sync();
     HHRL_STAMP(0, 2);
 
-    // ---- forward: func.0 (64 -> 128, ReLU)
-    f32x16 f1[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) f1[t] = splat(b0s[t * 32 + r]);
-    wave_mma<4, 64, 65, 1, 1, 65>(f1, cat, W0s, lane);
+    // ---- forward: func.0 = ReLU(U[lane] + loc * p)
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) f1[t][i] = fmaxf(f1[t][i], 0.f);
+      for (int i = 0; i < 16; ++i) f1[t][i] = fmaxf(fmaf(loc_i[i], p_t[t], f1[t][i]), 0.f);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) store_tile<129>(f1i, 32 * t, f1[t], lane);
+    wave_sync();
     HHRL_STAMP(0, 3);
 
-    // ---- forward: func.2 (128 -> 32, ReLU), f1 staged through the half image 64 features at a time
-    f32x16 f2[1];
-    f2[0] = splat(b2s[r]);
+    // ---- forward: func.2 (128 -> 32, ReLU)
+    {
+      f32x16 f2[1];
+      f2[0] = splat(b2s[r]);
+      wave_mma<1, 128, 129, 1, 1, 129>(f2, f1i, W2s, lane);
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      store_tile<65>(half, 0, f1[2 * hh], lane);
-      store_tile<65>(half, 32, f1[2 * hh + 1], lane);
-      wave_sync();
-      wave_mma<1, 64, 65, 1, 1, 129>(f2, half, W2s + 64 * hh, lane);
-      wave_sync();
+      for (int i = 0; i < 16; ++i) f2[0][i] = fmaxf(f2[0][i], 0.f);
+      store_tile<33>(f2i, 0, f2[0], lane);
     }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) f2[0][i] = fmaxf(f2[0][i], 0.f);
-    store_tile<33>(f2i, 0, f2[0], lane);
     wave_sync();
     HHRL_STAMP(0, 4);
 
@@ -238,85 +232,58 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
     HHRL_STAMP(0, 6);
 
     // ---- backward func.2: dW2 += df2^T f1 ; df1 = (df2 W2) o relu'(f1)
-    //      backward func.0: dW0 += df1^T cat ; dcat = df1 W0        (64 features of f1 at a time)
-    f32x16 dcat[2];
-    dcat[0] = splat(0.f);
-    dcat[1] = splat(0.f);
+    if (FIRST) {
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      store_tile<65>(half, 0, f1[2 * hh], lane);
-      store_tile<65>(half, 32, f1[2 * hh + 1], lane);
-      wave_sync();
-      {
-        f32x16 acc[2];
-        acc[0] = FIRST ? splat(0.f) : dW2[2 * hh];
-        acc[1] = FIRST ? splat(0.f) : dW2[2 * hh + 1];
-        wave_mma<2, 32, 1, 33, 65, 1>(acc, f2i, half, lane);
-        dW2[2 * hh] = acc[0];
-        dW2[2 * hh + 1] = acc[1];
-      }
-      f32x16 df1[2];
-      df1[0] = splat(0.f);
-      df1[1] = splat(0.f);
-      wave_mma<2, 32, 33, 1, 129, 1>(df1, f2i, W2s + 64 * hh, lane);
-      wave_sync();                         // all reads of the f1 half image are done
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        float cs = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const float dv = f1[2 * hh + t][i] > 0.f ? df1[t][i] : 0.f;
-          df1[t][i] = dv;
-          cs += dv;
-        }
-        db0[2 * hh + t] += cs;
-      }
-      store_tile<65>(half, 0, df1[0], lane);
-      store_tile<65>(half, 32, df1[1], lane);
-      wave_sync();
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        f32x16 acc[2];
-        acc[0] = FIRST ? splat(0.f) : dW0[2 * hh + it][0];
-        acc[1] = FIRST ? splat(0.f) : dW0[2 * hh + it][1];
-        wave_mma<2, 32, 1, 65, 65, 1>(acc, half + 32 * it, cat, lane);
-        dW0[2 * hh + it][0] = acc[0];
-        dW0[2 * hh + it][1] = acc[1];
-      }
-      wave_mma<2, 64, 65, 1, 65, 1>(dcat, half, W0s + 64 * hh * 65, lane);
-      wave_sync();
-      HHRL_STAMP(0, 7 + hh);
+      for (int t = 0; t < 4; ++t) dW2[t] = splat(0.f);
     }
-
-    // ---- loc embedding gradients from dcat[:, 32:64]
-    {
-      float sb = 0.f, sw = 0.f;
+    wave_mma<4, 32, 1, 33, 129, 1>(dW2, f2i, f1i, lane);
+    f32x16 df1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) df1[t] = splat(0.f);
+    wave_mma<4, 32, 33, 1, 129, 1>(df1, f2i, W2s, lane);
+    wave_sync();                           // all reads of the f1 image are done
+    HHRL_STAMP(0, 7);
+    // ---- ReLU mask of func.0, its column sums (db0, and s weighted by loc), df1 over the f1 image
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float cs = 0.f, ss = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        sb += dcat[1][i];
-        sw += dcat[1][i] * locs[drow(i, h)];
+        const float dv = f1[t][i] > 0.f ? df1[t][i] : 0.f;
+        df1[t][i] = dv;
+        cs += dv;
+        ss = fmaf(dv, loc_i[i], ss);
       }
-      blocacc += sb;
-      wlocacc += sw;
+      db0[t] += cs;
+      sacc[t] += ss;
+      store_tile<129>(f1i, 32 * t, df1[t], lane);
     }
-    // ---- gradient at the decoder output, summed per traffic lane within the tile on the matrix core:
-    //      P[s][col] = sum over the tile's cars of [lane of car == first lane of the tile + s] * dcat[car][col]
-    //      (exact: the indicator is 0 or 1, the cars of a lane add up in car order)
-    store_tile<33>(half, 0, dcat[0], lane);
     wave_sync();
+    HHRL_STAMP(0, 8);
+
+    // ---- df1 summed per traffic lane within the tile on the matrix core:
+    //      P[s][col] = sum over the tile's cars of [lane of car == first lane of the tile + s] * df1[car][col]
+    //      (exact: the indicator is 0 or 1, the cars of a lane add up in car order)
     {
-      const int b_first = __builtin_amdgcn_readfirstlane(in_b);
-      f32x16 P = splat(0.f);
+      f32x16 P[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) P[t] = splat(0.f);
 #pragma unroll
       for (int k = 0; k < 32; k += 2) {
-        const int b0 = __builtin_amdgcn_readlane(in_b, k), b1 = __builtin_amdgcn_readlane(in_b, k + 1);
-        const int bk = h ? b1 : b0;
-        const float a = (bk >= 0 && bk - b_first == r) ? 1.f : 0.f;
-        P = __builtin_amdgcn_mfma_f32_32x32x2f32(a, half[(k + h) * 33 + r], P, 0, 0, 0);
-      }
-      // every tile owns 32 rows of dpart; rows past its last traffic lane are zero and nobody reads them
+        const float a = ind[k >> 1];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) g.dpart[((long)tile * 32 + drow(i, h)) * 32 + r] = P[i];
+        for (int t = 0; t < 4; ++t)
+          P[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, f1i[(k + h) * 129 + 32 * t + r], P[t], 0, 0, 0);
+      }
+      // every tile owns R rows; a tile's rows past its last traffic lane are zero and nobody reads them
+      float* dst = g.spart + (long)tile * g.R * 128 + r;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (drow(i, h) < g.R) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) dst[drow(i, h) * 128 + 32 * t] = P[t][i];
+        }
+      }
     }
     wave_sync();
     HHRL_STAMP(0, 9);
@@ -328,62 +295,31 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
       for (int tile = tile0 + stride; tile < g.tiles; tile += stride) process_tile(std::false_type(), tile);
     } else {
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        dW0[a][0] = splat(0.f);
-        dW0[a][1] = splat(0.f);
-        dW2[a] = splat(0.f);
-      }
+      for (int a = 0; a < 4; ++a) dW2[a] = splat(0.f);
     }
   }
 
   // ---- combine the two lane halves (they hold different rows of the same columns)
 #pragma unroll
-  for (int t = 0; t < 4; ++t) db0[t] += __shfl_xor(db0[t], 32, 64);
+  for (int t = 0; t < 4; ++t) {
+    db0[t] += __shfl_xor(db0[t], 32, 64);
+    sacc[t] += __shfl_xor(sacc[t], 32, 64);
+  }
   w4acc += __shfl_xor(w4acc, 32, 64);
   db2acc += __shfl_xor(db2acc, 32, 64);
-  blocacc += __shfl_xor(blocacc, 32, 64);
-  wlocacc += __shfl_xor(wlocacc, 32, 64);
   b4acc = wave_sum(b4acc);
   lossacc = wave_sum(lossacc);
 
   // ---- combine the four waves in LDS in a fixed order.  Every image is dead by now: each wave stores
-  //      its tiles into a quarter of the LDS, all 256 threads then add the four quarters element-wise
-  //      ((w0 + w1) + (w2 + w3)) while writing the slab.  Two rounds: the func.0 gradient, then the rest.
+  //      its sums into a quarter buffer, all 256 threads then add the four quarters element-wise
+  //      ((w0 + w1) + (w2 + w3)) while writing the slab.
   __syncthreads();
   HHRL_STAMP(0, 10);
   float* slab = g.slab + (long)blockIdx.x * g.off.total;
-  constexpr int Q0 = 8192;                           // floats per wave in round one: dW0 [128][64]
-  static_assert(4 * Q0 <= CAR_LDS_FLOATS, "combine buffers must fit the workgroup's LDS");
-  {
-    float* mine = lds + wave * Q0;
-#pragma unroll
-    for (int it = 0; it < 4; ++it)
-#pragma unroll
-      for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) mine[(it * 32 + drow(i, h)) * 64 + jt * 32 + r] = dW0[it][jt][i];
-  }
-  __syncthreads();
-  auto sum4 = [](const float4& a, const float4& b, const float4& c, const float4& d) {
-    return make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
-  };
-  if (g.vec4) {                                      // 16-byte aligned slab and offsets (wave-uniform): four elements per access
-    const float4* q = reinterpret_cast<const float4*>(lds);
-    float4* dst = reinterpret_cast<float4*>(slab + g.off.w[FUNC0]);
-#pragma unroll
-    for (int u = 0; u < Q0 / 1024; ++u) {
-      const int i = u * 256 + tid;
-      dst[i] = sum4(q[i], q[Q0 / 4 + i], q[2 * (Q0 / 4) + i], q[3 * (Q0 / 4) + i]);
-    }
-  } else {
-    for (int i = tid; i < Q0; i += 256)
-      slab[g.off.w[FUNC0] + i] = (lds[i] + lds[Q0 + i]) + (lds[2 * Q0 + i] + lds[3 * Q0 + i]);
-  }
-  __syncthreads();
-  HHRL_STAMP(0, 11);
-  constexpr int B_W2 = 0, B_B0 = 4096, B_B2 = B_B0 + 128, B_W4 = B_B2 + 32, B_B4 = B_W4 + 32;
-  constexpr int B_WLOC = B_B4 + 1, B_BLOC = B_WLOC + 32, B_LOSS = B_BLOC + 32, Q1 = 4416;
-  static_assert(B_LOSS + 1 <= Q1 && 4 * Q1 <= CAR_LDS_FLOATS, "combine buffers must fit the workgroup's LDS");
+  constexpr int B_W2 = 0, B_B0 = 4096, B_S = B_B0 + 128, B_B2 = B_S + 128, B_W4 = B_B2 + 32, B_B4 = B_W4 + 32;
+  constexpr int B_LOSS = B_B4 + 1, Q1 = 4420;
+  constexpr int FIN = 4 * Q1;                        // s[128] db0[128], then partial products [8][64]
+  static_assert(B_LOSS + 1 <= Q1 && Q1 % 4 == 0 && FIN + 256 + 512 <= CAR_LDS_FLOATS, "combine buffers must fit the workgroup's LDS");
   {
     float* mine = lds + wave * Q1;
 #pragma unroll
@@ -392,11 +328,12 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
       for (int i = 0; i < 16; ++i) mine[B_W2 + drow(i, h) * 128 + jt * 32 + r] = dW2[jt][i];
     if (h == 0) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) mine[B_B0 + t * 32 + r] = db0[t];
+      for (int t = 0; t < 4; ++t) {
+        mine[B_B0 + t * 32 + r] = db0[t];
+        mine[B_S + t * 32 + r] = sacc[t];
+      }
       mine[B_B2 + r] = db2acc;
       mine[B_W4 + r] = w4acc;
-      mine[B_WLOC + r] = wlocacc;
-      mine[B_BLOC + r] = blocacc;
       if (r == 0) {
         mine[B_B4] = b4acc;
         mine[B_LOSS] = lossacc;
@@ -404,8 +341,12 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
     }
   }
   __syncthreads();
+  HHRL_STAMP(0, 11);
+  auto sum4 = [](const float4& a, const float4& b, const float4& c, const float4& d) {
+    return make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+  };
   auto all4 = [&](int i) { return (lds[i] + lds[Q1 + i]) + (lds[2 * Q1 + i] + lds[3 * Q1 + i]); };
-  if (g.vec4) {
+  if (g.vec4) {                                      // 16-byte aligned slab and offsets (wave-uniform): four elements per access
     const float4* q = reinterpret_cast<const float4*>(lds + B_W2);
     float4* dst = reinterpret_cast<float4*>(slab + g.off.w[FUNC2]);
 #pragma unroll
@@ -416,16 +357,43 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
   } else {
     for (int i = tid; i < 4096; i += 256) slab[g.off.w[FUNC2] + i] = all4(B_W2 + i);
   }
-  if (tid < 128) slab[g.off.b[FUNC0] + tid] = all4(B_B0 + tid);
+  float* fin = lds + FIN;
+  if (tid < 128) {
+    const float sv = all4(B_S + tid);
+    fin[tid] = sv;
+    slab[g.off.w[FUNC0] + tid * 64 + 32] = sv;       // s[o] travels in the first position of row o that no sum uses
+  } else {
+    const float dv = all4(B_B0 + tid - 128);
+    fin[tid] = dv;
+    slab[g.off.b[FUNC0] + tid - 128] = dv;
+  }
   if (tid < 32) {
     slab[g.off.b[FUNC2] + tid] = all4(B_B2 + tid);
     slab[g.off.w[FUNC4] + tid] = all4(B_W4 + tid);
-    slab[g.off.w[LOC] + tid] = all4(B_WLOC + tid);
-    slab[g.off.b[LOC] + tid] = all4(B_BLOC + tid);
   }
   if (tid == 0) {
     slab[g.off.b[FUNC4]] = all4(B_B4);
     g.loss_part[blockIdx.x] = all4(B_LOSS);
+  }
+  __syncthreads();
+  // ---- loc embedding: dwloc[j] = sum_o s[o] W0[o][32 + j], dbloc[j] = sum_o db0[o] W0[o][32 + j]
+  //      (this workgroup's share; eight groups of sixteen o each, combined in a fixed order)
+  {
+    const int j = tid & 31, og = tid >> 5;
+    float pw = 0.f, pb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      pw = fmaf(fin[16 * og + k], w0e[k], pw);
+      pb = fmaf(fin[128 + 16 * og + k], w0e[k], pb);
+    }
+    fin[256 + og * 64 + j] = pw;
+    fin[256 + og * 64 + 32 + j] = pb;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const float* pp = fin + 256 + tid;
+    const float sum = ((pp[0] + pp[64]) + (pp[128] + pp[192])) + ((pp[256] + pp[320]) + (pp[384] + pp[448]));
+    slab[(tid < 32 ? g.off.w[LOC] + tid : g.off.b[LOC] + tid - 32)] = sum;
   }
   HHRL_STAMP(0, 12);
 }
@@ -447,13 +415,14 @@ struct LaneArgs {
   const float* eps;    // [B][g]
   const float* w[NLAYER];
   const float* b[NLAYER];
-  float* d2;           // [B][32] forward output
+  float* u;            // [B][128] forward output: func.0 pre-activation of the lane's cars without the position term
+  float* aux;          // forward output: p[128] = W0[:, 32:] wloc, then copies of wloc[32] and bloc[32]
   float* act;          // [tiles][LN_ACT_FLOATS] activation images: written by the forward, read by the backward kernel
-  const float* dpart;  // [car tiles * 32][32] backward input: gradient at d2, one row per (car tile, traffic lane in it)
+  const float* spart;  // [car tiles * R][128] backward input: df1 summed per (car tile, traffic lane in it)
   float* slab;
   float* kl_part;      // [gridDim.x]
   Offsets off;
-  int B, N, g, tiles;
+  int B, N, g, tiles, R;
 };
 
 
@@ -466,7 +435,8 @@ constexpr int LW_DEC0 = LW_HEAD + 32 * 65;        // [128][17]  columns >= g zer
 constexpr int LW_DEC2 = LW_DEC0 + 128 * 17;       // [32][129]
 constexpr int LW_BIAS = LW_DEC2 + 32 * 129;       // phi2[32] rho0[128] rho2[64] head[32] dec0[128] dec2[32]
 constexpr int LB_PHI2 = 0, LB_RHO0 = 32, LB_RHO2 = 160, LB_HEAD = 224, LB_DEC0 = 256, LB_DEC2 = 384, LB_END = 416;
-constexpr int LI_H1 = LW_BIAS + LB_END;           // [32][33]  summed hidden of phi (16 columns used)
+constexpr int LB_Q = LB_END, LB_ALL = LB_Q + 128; // q[128] = b0 + W0[:, 32:] bloc (forward kernel only)
+constexpr int LI_H1 = LW_BIAS + LB_ALL;           // [32][33]  summed hidden of phi (16 columns used)
 constexpr int LI_POOL = LI_H1 + 32 * 33;          // [32][33]
 constexpr int LI_R1 = LI_POOL + 32 * 33;          // [32][129]
 constexpr int LI_R2 = LI_R1 + 32 * 129;           // [32][65]
@@ -480,7 +450,7 @@ constexpr int LI_CARS = LI_TMP + 32 * 33;         // the tile's car states, 32 l
 constexpr int STAGE_MAX_CARS = 16;
 constexpr int LN_LDS_FLOATS = LI_CARS + 64 * STAGE_MAX_CARS;
 static_assert(LN_LDS_FLOATS * 4 <= 163840 - 64, "per-lane kernels must fit the 160 KiB LDS");
-constexpr int LN_ACT_FLOATS = LI_D2 - LI_H1;      // h1 | pooled | r1 | r2 | mean,logvar | z | d1, verbatim
+constexpr int LN_ACT_FLOATS = LI_DML - LI_H1;     // h1 | pooled | r1 | r2 | mean,logvar | z | d1 | d2, verbatim
 static_assert(LI_H1 % 4 == 0 && LN_ACT_FLOATS % 4 == 0, "activation images are copied 16 bytes at a time");
 constexpr int ACT_V4 = LN_ACT_FLOATS / 4;
 
@@ -643,14 +613,15 @@ struct ActRange {
       v[u] = i4 < V4 ? src[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  __device__ __forceinline__ void commit(float* lds, int tid) const {
-    float4* dst = reinterpret_cast<float4*>(lds + LO);
+  __device__ __forceinline__ void commit_at(float* slot, int tid) const {   // slot: 16-byte aligned
+    float4* dst = reinterpret_cast<float4*>(slot);
 #pragma unroll
     for (int u = 0; u < STEPS; ++u) {
       const int i4 = u * NT + tid;
       if (i4 < V4) dst[i4] = v[u];
     }
   }
+  __device__ __forceinline__ void commit(float* lds, int tid) const { commit_at(lds + LO, tid); }
 };
 
 // ------------------------------------------------------------------ forward
@@ -685,10 +656,42 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_forward_kernel(LaneArgs g) {
   request_P(rP, g, blockIdx.x * 32, tid);
   request_R(rR, g, tid);
   request_D(rD, g, tid);
+  // func.0's columns for d2, as the B operand of the last product: row 32 wave + r, elements 16 h .. 16 h + 15
+  // (step s of the product takes k = 16 h + s from both operands)
+  float4 w0a[4];
+  if (mat) {
+    const float4* src = reinterpret_cast<const float4*>(g.w[FUNC0] + (32 * wave + r) * 64 + 16 * (lane >> 5));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w0a[e] = src[e];
+  }
+  // the position part of func.0, by the last 128 threads (output o each): p = E wloc, q = b0 + E bloc
+  // with E = W0[:, 32:]
+  float4 w0e[8];
+  float b0o = 0.f;
+  const int o_pq = tid - (NT - 128);
+  if (o_pq >= 0) {
+    const float4* src = reinterpret_cast<const float4*>(g.w[FUNC0] + o_pq * 64 + 32);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) w0e[e] = src[e];
+    b0o = g.b[FUNC0][o_pq];
+  }
   commit_bias(lds, rB, tid);
   commit_P(lds, rP, g, tid);
   commit_R(lds, rR, g, tid);
   commit_D(lds, rD, g, tid);
+  if (o_pq >= 0) {
+    float pv = 0.f, qv = b0o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float* wl4 = g.w[LOC] + 4 * e;
+      const float* bl4 = g.b[LOC] + 4 * e;
+      pv += w0e[e].x * wl4[0] + w0e[e].y * wl4[1] + w0e[e].z * wl4[2] + w0e[e].w * wl4[3];
+      qv += w0e[e].x * bl4[0] + w0e[e].y * bl4[1] + w0e[e].z * bl4[2] + w0e[e].w * bl4[3];
+    }
+    bs[LB_Q + o_pq] = qv;
+    if (blockIdx.x == 0) g.aux[o_pq] = pv;
+  }
+  if (blockIdx.x == 0 && tid < 64) g.aux[128 + tid] = tid < 32 ? g.w[LOC][tid] : g.b[LOC][tid - 32];
   __syncthreads();
   HHRL_STAMP(1, 1);
   for (int tile = blockIdx.x; tile < g.tiles; tile += gridDim.x) {
@@ -788,8 +791,26 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_forward_kernel(LaneArgs g) {
     }
     __syncthreads();
     HHRL_STAMP(1, 10);
-    // ---- outputs: d2 rows for the per-car kernel, the activation images for the backward kernel
-    store_rows32<NT>(Id2, g.d2, row0, g.B, tid);
+    // ---- outputs: U = d2 A^T + q for the per-car kernel (A = W0[:, :32]; column tile `wave`, straight from
+    //      the accumulators), the activation images for the backward kernel
+    if (mat) {
+      f32x16 acc = splat(bs[LB_Q + wave * 32 + r]);
+      const float* ap = Id2 + r * 33 + 16 * (lane >> 5);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[4 * e], w0a[e].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[4 * e + 1], w0a[e].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[4 * e + 2], w0a[e].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[4 * e + 3], w0a[e].w, acc, 0, 0, 0);
+      }
+      float* dst = g.u + (long)row0 * 128 + 32 * wave + r;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int rr = drow(i, lane >> 5);
+        if (row0 + rr < g.B) dst[rr * 128] = acc[i];
+      }
+    }
+    HHRL_STAMP(1, 11);
     {
       float4* dst = reinterpret_cast<float4*>(g.act + (long)tile * LN_ACT_FLOATS);
       const float4* src = reinterpret_cast<const float4*>(lds + LI_H1);
@@ -800,7 +821,7 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_forward_kernel(LaneArgs g) {
       }
     }
     __syncthreads();
-    HHRL_STAMP(1, 11);
+    HHRL_STAMP(1, 12);
   }
 }
 
@@ -1071,7 +1092,9 @@ __device__ __forceinline__ float slab_quarter_sum(const float* __restrict__ col,
 // reduction kernel at the end of the step only has the per-lane layers left.
 struct CarReduce {
   const float* slab;
-  long total, lo, hi;
+  long total, lo, hi;                 // columns [lo, hi) without [hole_lo, hole_hi): func.0's matrix waits for the per-lane slabs
+  long hole_lo, hole_hi;
+  float* svec;                        // [128] out: s[o] (slab position hole_lo + o*64 + 32) summed over the slabs
   float *grads, *params, *m, *v;      // params == nullptr: gradients only
   AdamK k;
   int n_car, first_block, n_blocks;   // workgroups first_block .. first_block + n_blocks - 1 do this work; n_blocks 0: off
@@ -1080,19 +1103,25 @@ struct CarReduce {
 // 512 threads: two groups of 64 columns, four waves (slab quarters) each; `red` = 512 floats of LDS
 __device__ __forceinline__ void car_reduce_block(const CarReduce& R, int blk, int tid, float* red) {
   const int group = tid >> 8, q = (tid >> 6) & 3, p = tid & 63;
-  const long ngroups = (R.hi - R.lo + 63) / 64;
+  const long before = (R.hole_lo - R.lo + 63) / 64;             // groups in front of the hole
+  const long ncols = before + (R.hi - R.hole_hi + 63) / 64;     // groups of parameter columns
+  const long ngroups = ncols + 2;                               // and two groups for the 128 entries of s
   for (long base = 2L * blk; base < ngroups; base += 2L * R.n_blocks) {
-    const long i = R.lo + (base + group) * 64 + p;
-    const bool live = i < R.hi;
+    const long gi64 = base + group;
+    const bool sgrp = gi64 >= ncols;
+    const long i = sgrp ? R.hole_lo + ((gi64 - ncols) * 64 + p) * 64 + 32
+                        : (gi64 < before ? R.lo + gi64 * 64 + p : R.hole_hi + (gi64 - before) * 64 + p);
+    const bool live = sgrp ? gi64 < ngroups : (gi64 < before ? i < R.hole_lo : i < R.hi);
     red[(group * 4 + q) * 64 + p] = live ? slab_quarter_sum(R.slab + i, R.total, R.n_car, q) : 0.f;
     __syncthreads();
     if (q == 0 && live) {
       const float* rg = red + group * 256;
-      const float gi = (rg[p] + rg[64 + p]) + (rg[128 + p] + rg[192 + p]);
-      R.grads[i] = gi;
-      if (R.params != nullptr) {
+      const float gsum = (rg[p] + rg[64 + p]) + (rg[128 + p] + rg[192 + p]);
+      if (sgrp) R.svec[(gi64 - ncols) * 64 + p] = gsum;
+      else R.grads[i] = gsum;
+      if (!sgrp && R.params != nullptr) {
         float pi = R.params[i], mi = R.m[i], vi = R.v[i];
-        adam_one(pi, gi, mi, vi, R.k);
+        adam_one(pi, gsum, mi, vi, R.k);
         R.params[i] = pi;
         R.m[i] = mi;
         R.v[i] = vi;
@@ -1121,14 +1150,14 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
   const int gd = g.g;
   float* Ih1 = lds + LI_H1;
   float* Ipool = lds + LI_POOL;
-  float* Ir1 = lds + LI_R1;     // r1, then dr1
+  float* Ir1 = lds + LI_R1;     // S (df1 summed per lane) until dd2 and dA are formed, then r1, then dr1
   float* Ir2 = lds + LI_R2;     // r2, then dr2, then scratch of the phi.0 backward
   float* Iml = lds + LI_ML;     // mean|logvar, then dpooled
   float* Iz = lds + LI_Z;
   float* Id1 = lds + LI_D1;     // d1, then dd1
   float* Id2 = lds + LI_D2;     // dd2
   float* Idml = lds + LI_DML;
-  float* Itmp = lds + LI_TMP;   // dz, then t = dpooled * W_phi2
+  float* Itmp = lds + LI_TMP;   // d2 (forward value) until dA is formed, then dz, then t = dpooled * W_phi2
   const bool staged = g.N <= STAGE_MAX_CARS;
   const bool mat = wave < 4;                      // this wave takes part in the matrix phases
   HHRL_STAMP(2, 0);
@@ -1137,7 +1166,7 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
 
   // weight-gradient tiles owned by this wave, kept across tiles
   f32x16 aDec2 = splat(0.f), aDec0 = splat(0.f), aHead = splat(0.f), aRho2a = splat(0.f), aRho2b = splat(0.f);
-  f32x16 aRho0 = splat(0.f), aPhi2 = splat(0.f);
+  f32x16 aRho0 = splat(0.f), aPhi2 = splat(0.f), aF0 = splat(0.f);
   // bias gradients: one thread owns a column of a layer
   float bDec2 = 0.f, bDec0 = 0.f, bHead = 0.f, bRho2 = 0.f, bRho0 = 0.f, bPhi2 = 0.f;
   float gPhi0a = 0.f, gPhi0b = 0.f, gPhi0c = 0.f;     // threads 0..47: dW_phi0[k][0], dW_phi0[k][1], db_phi0[k]
@@ -1153,6 +1182,9 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
     }
   };
 
+  auto write_f0 = [&]() {     // columns 0..31 of func.0's rows 32 wave .. 32 wave + 31
+    put_tile(g.off.w[FUNC0] + (long)32 * wave * 64, 64, 32, 0, 32, aF0);
+  };
   auto write_dec2 = [&]() {
     put_tile(g.off.w[DEC2], 128, 32, 32 * wave, 128, aDec2);
     if (tid < 32) slab[g.off.b[DEC2] + tid] = bDec2;
@@ -1222,63 +1254,95 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
       const int idx = u * NT + tid, rr = idx >> 5, c = idx & 31;
       eps_r[u] = (c >= gd && c < 2 * gd && row0 + rr < g.B) ? g.eps[(long)(row0 + rr) * gd + c - gd] : 0.f;
     }
-    // dd2 of a traffic lane = sum of the per-(lane, car tile) partial rows of the car tiles its cars span,
-    // in tile order.  The first two tiles (all there are when N <= 33) are read from clamped addresses
-    // without a branch, so the eight round trips of a thread overlap; longer lanes loop over the rest.
-    float dd2v[1024 / NT];
+    // S of a traffic lane = sum of the per-(car tile, lane) rows of the car tiles its cars span, in tile
+    // order.  A thread owns one lane and CPT columns of it.  The first two tiles (all there are when
+    // N <= 33) are read from clamped addresses without a branch, so the round trips of a thread overlap;
+    // longer lanes loop over the rest.
+    constexpr int TPR = NT / 32, CPT = 128 / TPR;        // threads per lane row, columns per thread
+    float4 sv[CPT / 4];
+    const int s_row = tid / TPR, s_col = 4 * (tid % TPR);
     {
-      const unsigned n = (unsigned)g.N;
-      float p0[1024 / NT], p1[1024 / NT];
-      unsigned t0s[1024 / NT], t1s[1024 / NT];
-      bool ok0[1024 / NT], ok1[1024 / NT];
+      const unsigned n = (unsigned)g.N, R = (unsigned)g.R;
+      const int b = row0 + s_row;
+      const unsigned lo = (unsigned)b * n;
+      const unsigned t0 = lo >> 5, t1 = (lo + n - 1) >> 5;
+      const bool ok0 = b < g.B, ok1 = ok0 && t1 > t0;
+      const long a0 = ((long)t0 * R + ((unsigned)b - (t0 * 32u) / n)) * 128;
+      const long a1 = ((long)(t0 + 1) * R + ((unsigned)b - ((t0 + 1) * 32u) / n)) * 128;
+      const float4* q0 = reinterpret_cast<const float4*>(g.spart + (ok0 ? a0 : 0) + s_col);
+      const float4* q1 = reinterpret_cast<const float4*>(g.spart + (ok1 ? a1 : 0) + s_col);
+      float4 p0[CPT / 4], p1[CPT / 4];
 #pragma unroll
-      for (int u = 0; u < 1024 / NT; ++u) {
-        const int idx = u * NT + tid, rr = idx >> 5, c = idx & 31;
-        const int b = row0 + rr;
-        const unsigned lo = (unsigned)b * n;
-        const unsigned t0 = lo >> 5, t1 = (lo + n - 1) >> 5;
-        ok0[u] = b < g.B;
-        ok1[u] = ok0[u] && t1 > t0;
-        t0s[u] = t0;
-        t1s[u] = t1;
-        const long a0 = ((long)t0 * 32 + ((unsigned)b - (t0 * 32u) / n)) * 32 + c;
-        const long a1 = ((long)(t0 + 1) * 32 + ((unsigned)b - ((t0 + 1) * 32u) / n)) * 32 + c;
-        p0[u] = g.dpart[ok0[u] ? a0 : c];
-        p1[u] = g.dpart[ok1[u] ? a1 : c];
+      for (int u = 0; u < CPT / 4; ++u) {
+        p0[u] = q0[u * TPR];
+        p1[u] = q1[u * TPR];
       }
 #pragma unroll
-      for (int u = 0; u < 1024 / NT; ++u) {
-        float sum = ok0[u] ? p0[u] : 0.f;
-        if (ok1[u]) sum += p1[u];
-        if (ok1[u] && t1s[u] > t0s[u] + 1) {
-          const int idx = u * NT + tid, rr = idx >> 5, c = idx & 31;
-          const unsigned b = (unsigned)(row0 + rr);
-          for (unsigned t = t0s[u] + 2; t <= t1s[u]; ++t) sum += g.dpart[((long)t * 32 + (b - (t * 32u) / n)) * 32 + c];
+      for (int u = 0; u < CPT / 4; ++u) {
+        float4 sum = ok0 ? p0[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok1) { sum.x += p1[u].x; sum.y += p1[u].y; sum.z += p1[u].z; sum.w += p1[u].w; }
+        if (ok1 && t1 > t0 + 1) {
+          for (unsigned t = t0 + 2; t <= t1; ++t) {
+            const float4 e = *reinterpret_cast<const float4*>(g.spart + ((long)t * R + ((unsigned)b - (t * 32u) / n)) * 128 + s_col + 4 * u * TPR);
+            sum.x += e.x; sum.y += e.y; sum.z += e.z; sum.w += e.w;
+          }
         }
-        dd2v[u] = sum;
+        sv[u] = sum;
       }
     }
+    // func.0's columns for d2 as the B operand of dd2 = S A (16x16 blocks, step s takes k = 4 s + lane / 16)
+    // (requested here when a workgroup has one tile; the multi-tile form has no registers to spare for
+    // it during the copies and asks after them)
+    float w0r[32];
+    auto request_w0r = [&]() {
+      const float* src = g.w[FUNC0] + (lane >> 4) * 64 + 16 * cb + (lane & 15);
+#pragma unroll
+      for (int s2 = 0; s2 < 32; ++s2) w0r[s2] = src[s2 * 256];
+    };
+    if (SINGLE && mat) request_w0r();
+    ActRange<LI_D2, LI_DML, NT> actO;   // d2
+    actO.request(act_tile, tid);
     actR.request(act_tile, tid);
     if (first) request_R(rR, g, tid);
     actP.request(act_tile, tid);
     if (first) request_P(rP, g, row0, tid); else request_cars<NT>(rP.cars, g, row0, tid);
-    // ---- and write it to LDS
+    // ---- and write it to LDS (S takes the slot of r1 until it has been used; r1 and r2 wait in registers)
 #pragma unroll
-    for (int u = 0; u < 1024 / NT; ++u) {
-      const int idx = u * NT + tid;
-      Id2[(idx >> 5) * 33 + (idx & 31)] = dd2v[u];
+    for (int u = 0; u < CPT / 4; ++u) {
+      float* q = Ir1 + s_row * 129 + s_col + 4 * u * TPR;
+      q[0] = sv[u].x; q[1] = sv[u].y; q[2] = sv[u].z; q[3] = sv[u].w;
     }
+    actO.commit_at(Itmp, tid);
     actD.commit(lds, tid);
     if (first) {
       commit_bias(lds, rB, tid);
       commit_D(lds, rD, g, tid);
     }
-    actR.commit(lds, tid);
     if (first) commit_R(lds, rR, g, tid);
     actP.commit(lds, tid);
     if (first) commit_P(lds, rP, g, tid); else commit_cars<NT>(lds, rP.cars, g, tid);
     __syncthreads();
     HHRL_STAMP(2, 1);
+    // ---- func.0, the part shared by a lane's cars: dd2 = S A (16x16 blocks), dA[128][32] += S^T d2 (row tile `wave`)
+    if (mat) {
+      if (!SINGLE) request_w0r();
+      const int q4 = lane >> 4;
+      const float* ap = Ir1 + (16 * rb + (lane & 15)) * 129 + q4;
+      f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s2 = 0; s2 < 32; s2 += 2) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s2], w0r[s2], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s2 + 4], w0r[s2 + 1], c1, 0, 0, 0);
+      }
+      store_block16<33>(Id2, 16 * rb, 16 * cb, c0 + c1, lane);
+      f32x16 acc[1] = {aF0};
+      wave_mma<1, 32, 1, 129, 33, 1>(acc, Ir1 + 32 * wave, Itmp, lane);
+      aF0 = acc[0];
+    }
+    if (SINGLE && mat) write_f0();
+    __syncthreads();
+    HHRL_STAMP(2, 2);
+    actR.commit(lds, tid);               // r1 over S, r2: first read after the next barriers
     // ---- decoder.2 backward: dW[32][128] += dd2^T d1, db, dd1 = (dd2 W) o relu'(d1) in place (column block `wave`)
     if (mat) {
       f32x16 acc[1] = {aDec2};
@@ -1297,7 +1361,7 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
     }
     if (SINGLE && mat) write_dec2();
     __syncthreads();
-    HHRL_STAMP(2, 2);
+    HHRL_STAMP(2, 3);
     // ---- decoder.0 backward: dW[128][g] += dd1^T z (row tile `wave`), db, dz = dd1 W (waves 0 and 1, 16 rows each)
     if (mat) {
       f32x16 acc[1] = {aDec0};
@@ -1312,7 +1376,7 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
     }
     if (SINGLE && mat) write_dec0();
     __syncthreads();
-    HHRL_STAMP(2, 3);
+    HHRL_STAMP(2, 4);
     // ---- latent gradient (KL + reparameterisation): dml = [dz + mean | dz*eps*0.5*std + 0.5*(exp(lv)-1) | 0...]
 #pragma unroll
     for (int u = 0; u < 1024 / NT; ++u) {
@@ -1332,7 +1396,7 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
       Idml[rr * 33 + c] = outv;
     }
     __syncthreads();
-    HHRL_STAMP(2, 4);
+    HHRL_STAMP(2, 5);
     // ---- heads backward: dW[2g][64] += dml^T r2 (waves 0,1), dr2 = dml W (waves 2,3; replaces r2 afterwards)
     {
       f32x16 d[1];
@@ -1350,7 +1414,7 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
     }
     if (SINGLE && mat) write_heads();
     __syncthreads();
-    HHRL_STAMP(2, 5);
+    HHRL_STAMP(2, 6);
     // ---- rho.2 backward: dW[64][128] += dr2^T r1 (two tiles per wave), db, dr1 = (dr2 W) o relu'(r1) in place
     {
       f32x16 d[1];
@@ -1375,7 +1439,7 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
     }
     if (SINGLE && mat) write_rho2();
     __syncthreads();
-    HHRL_STAMP(2, 6);
+    HHRL_STAMP(2, 7);
     // ---- rho.0 backward: dW[128][32] += dr1^T pooled (row tile `wave`), db, dpooled = dr1 W (16x16 blocks) -> ml slot
     if (mat) {
       f32x16 acc[1] = {aRho0};
@@ -1387,7 +1451,7 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
     }
     if (SINGLE && mat) write_rho0();
     __syncthreads();
-    HHRL_STAMP(2, 7);
+    HHRL_STAMP(2, 8);
     // ---- phi.2 backward on the summed hidden: dW[32][16] += dpooled^T h1s (wave 0), db = N colsum(dpooled) (wave 1),
     //      t = dpooled W_phi2 (waves 2 and 3): gradient at the hidden layer of every car of the lane, before its ReLU mask
     if (wave == 0) {
@@ -1402,7 +1466,7 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
     }
     if (SINGLE && mat) write_phi2();
     __syncthreads();
-    HHRL_STAMP(2, 8);
+    HHRL_STAMP(2, 9);
     // ---- phi.0 backward: per (lane, hidden unit) walk the cars again and apply the ReLU mask
     {
       float* red = Ir2;       // [32][49] partial sums
@@ -1430,10 +1494,11 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
       }
     }
     __syncthreads();
-    HHRL_STAMP(2, 9);
+    HHRL_STAMP(2, 10);
   } while (!SINGLE && (tile += gridDim.x) < g.tiles);
 
   if (!SINGLE) {
+    write_f0();
     write_dec2();
     write_dec0();
     write_heads();
@@ -1459,31 +1524,57 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
     for (int w = 1; w < NT / 64; ++w) kl += klred[w];
     g.kl_part[blockIdx.x] = kl;
   }
-  HHRL_STAMP(2, 10);
+  HHRL_STAMP(2, 11);
 }
 
 // grads[i] = sum over slabs, in a fixed order: the same inputs give the same bits.
 // A workgroup owns 64 consecutive parameters; its four waves each sum a quarter of the
-// slabs (four independent running sums keep loads in flight), LDS combines the quarters.
+// slabs (eight independent running sums keep loads in flight), LDS combines the quarters.
+// func.0's matrix [128][64] at f0_lo: columns 0..31 of a row are sums over the per-lane slabs, columns
+// 32 + j are s[o] wloc[j] + db0[o] bloc[j] with s[o] (slab position o*64 + 32) and db0[o] (position
+// b0_off + o) summed over the per-car slabs (or taken from svec and grads when those sums exist already) and
+// wloc | bloc as they were at the start of the step (locsave).
 __global__ __launch_bounds__(256) void vae_reduce_grads_kernel(const float* __restrict__ slab, long total, int n_car, int n_lane,
-                                                               long car_lo, long car_hi, long skip_lo, long skip_hi, float* grads,
+                                                               long car_lo, long car_hi, long f0_lo, long b0_off,
+                                                               const float* __restrict__ locsave, const float* __restrict__ svec,
+                                                               long skip_lo, long skip_mid,
+                                                               long skip_back, long skip_hi, float* grads,
                                                                const float* __restrict__ loss_part, const float* __restrict__ kl_part,
                                                                float* loss, float* params, float* m, float* v, AdamK k) {
-  __shared__ float red[4][64];
+  __shared__ float red[2][4][64];
   const int p = threadIdx.x & 63, q = threadIdx.x >> 6;
   const long i0 = (long)blockIdx.x * 64;
-  if (i0 >= skip_lo && i0 < skip_hi) return;           // columns already summed beside the per-lane backward kernel
+  // columns already summed beside the per-lane backward kernel: [skip_lo, skip_mid) and [skip_back, skip_hi)
+  if ((i0 >= skip_lo && i0 < skip_mid) || (i0 >= skip_back && i0 < skip_hi)) return;
   const long i = i0 + p;
-  float s = 0.f;
-  if (i < total) {
-    // per-car layers (loc, func.*) occupy [car_lo, car_hi) and come from the per-car kernel's slabs
-    const int n = (i >= car_lo && i < car_hi) ? n_car : n_lane;
-    s = slab_quarter_sum(slab + i, total, n, q);
+  const long e = i - f0_lo;
+  const bool derived = e >= 0 && e < 8192 && (e & 63) >= 32;
+  float s = 0.f, s2 = 0.f;
+  if (derived) {
+    const long o = e >> 6;
+    if (svec != nullptr) {                               // both sums were formed beside the per-lane backward kernel
+      s = q == 0 ? svec[o] : 0.f;
+      s2 = q == 0 ? grads[b0_off + o] : 0.f;
+    } else {
+      s = slab_quarter_sum(slab + f0_lo + o * 64 + 32, total, n_car, q);
+      s2 = slab_quarter_sum(slab + b0_off + o, total, n_car, q);
+    }
+  } else if (i < total) {
+    // per-car layers (loc, func.*) occupy [car_lo, car_hi) and come from the per-car kernel's slabs,
+    // except the first 32 columns of func.0's rows
+    const bool car = i >= car_lo && i < car_hi && !(e >= 0 && e < 8192);
+    s = slab_quarter_sum(slab + i, total, car ? n_car : n_lane, q);
   }
-  red[q][p] = s;
+  red[0][q][p] = s;
+  red[1][q][p] = s2;
   __syncthreads();
   if (q == 0 && i < total) {
-    const float gi = (red[0][p] + red[1][p]) + (red[2][p] + red[3][p]);
+    float gi = (red[0][0][p] + red[0][1][p]) + (red[0][2][p] + red[0][3][p]);
+    if (derived) {
+      const float di = (red[1][0][p] + red[1][1][p]) + (red[1][2][p] + red[1][3][p]);
+      const int j = (int)(e & 31);
+      gi = gi * locsave[j] + di * locsave[32 + j];
+    }
     grads[i] = gi;
     if (params != nullptr) {                           // fused optimizer step (single device)
       float pi = params[i], mi = m[i], vi = v[i];
@@ -1495,15 +1586,15 @@ __global__ __launch_bounds__(256) void vae_reduce_grads_kernel(const float* __re
   }
   if (blockIdx.x == 0 && threadIdx.x < 64) {
     float t = 0.f;
-    for (int k = threadIdx.x; k < n_car; k += 64) t += loss_part[k];
-    for (int k = threadIdx.x; k < n_lane; k += 64) t += kl_part[k];
+    for (int kk = threadIdx.x; kk < n_car; kk += 64) t += loss_part[kk];
+    for (int kk = threadIdx.x; kk < n_lane; kk += 64) t += kl_part[kk];
     t = wave_sum(t);
     if (threadIdx.x == 0) *loss = t;
   }
 }
 
 struct Ws {
-  float *d2, *dpart, *act, *loss_part, *kl_part, *slab;
+  float *u, *aux, *spart, *act, *loss_part, *kl_part, *slab;
   long total;
 };
 
@@ -1525,8 +1616,9 @@ static Ws carve(float* ws, int B, int N, int g, long n_flat) {
   Ws w;
   long off = 0;
   auto take = [&](long n) { float* p = ws ? ws + off : nullptr; off += a64(n); return p; };
-  w.d2 = take((long)B * 32);
-  w.dpart = take(((long)B * N + 31) / 32 * 32 * 32);
+  w.u = take((long)B * 128);
+  w.aux = take(320);   // p[128] | wloc[32] bloc[32] as the step found them | s[128]
+  w.spart = take(((long)B * N + 31) / 32 * lanes_per_car_tile(N) * 128);
   w.act = take((long)((B + 31) / 32) * LN_ACT_FLOATS);
   w.loss_part = take(256);
   w.kl_part = take(256);
@@ -1571,11 +1663,16 @@ static int vae_step_impl(float* params, float* grads, float* m, float* v, const 
     const long nb = numel_b[l] < 0 ? g : numel_b[l];
     HHRL_REQUIRE(off.w[l] >= 0 && off.w[l] + nw <= n_flat && off.b[l] >= 0 && off.b[l] + nb <= n_flat,
                  "vae_train_step: offsets[%d] outside the flat buffer", l);
+    HHRL_REQUIRE((off.w[l] & 3) == 0, "vae_train_step: weight %d is not 16-byte aligned inside the flat buffer", l);
   }
+  HHRL_REQUIRE(reinterpret_cast<uintptr_t>(params) % 16 == 0 && reinterpret_cast<uintptr_t>(ws) % 16 == 0,
+               "vae_train_step: params and ws must be 16-byte aligned");
   off.total = n_flat;
   // per-car layers must be contiguous at the end of the layout (loc, func.0, func.2, func.4)
   const long car_lo = off.w[LOC], car_hi = off.b[FUNC4] + 1;
-  HHRL_REQUIRE(car_lo > off.b[DEC2] && off.w[FUNC0] > car_lo && off.b[FUNC4] > off.w[FUNC0],
+  const long f0_lo = off.w[FUNC0], f0_hi = f0_lo + 8192, b0_off = off.b[FUNC0];
+  HHRL_REQUIRE(car_lo > off.b[DEC2] && off.b[LOC] > car_lo && f0_lo > off.b[LOC] && b0_off >= f0_hi && off.w[FUNC2] > b0_off &&
+                   off.b[FUNC4] > off.w[FUNC2],
                "vae_train_step: unexpected parameter order");
   hipStream_t st = as_stream(stream);
   Ws w = carve(ws, B, N, g, n_flat);
@@ -1609,13 +1706,15 @@ static int vae_step_impl(float* params, float* grads, float* m, float* v, const 
     la.w[l] = params + off.w[l];
     la.b[l] = params + off.b[l];
   }
-  la.d2 = w.d2;
-  la.dpart = w.dpart;
+  la.u = w.u;
+  la.aux = w.aux;
+  la.spart = w.spart;
   la.act = w.act;
   la.slab = w.slab;
   la.kl_part = w.kl_part;
   la.off = off;
   la.B = B; la.N = N; la.g = g; la.tiles = (B + 31) / 32;
+  la.R = lanes_per_car_tile(N);
 
   const double lane_macs = 16.0 * 2 * N + 512 + 4096 + 8192 + 128.0 * g + 128.0 * g + 4096;
   {
@@ -1629,22 +1728,24 @@ static int vae_step_impl(float* params, float* grads, float* m, float* v, const 
 
   CarArgs ca;
   ca.data = data;
-  ca.d2 = w.d2;
-  ca.wloc = la.w[LOC]; ca.bloc = la.b[LOC];
-  ca.w0 = la.w[FUNC0]; ca.b0 = la.b[FUNC0];
+  ca.u = w.u;
+  ca.pvec = w.aux;
+  ca.w0 = la.w[FUNC0];
   ca.w2 = la.w[FUNC2]; ca.b2 = la.b[FUNC2];
   ca.w4 = la.w[FUNC4]; ca.b4 = la.b[FUNC4];
-  ca.dpart = w.dpart;
+  ca.spart = w.spart;
   ca.slab = w.slab;
   ca.loss_part = w.loss_part;
   ca.off = off;
   ca.rows = rows;
   ca.N = N;
   ca.tiles = (int)((rows + 31) / 32);
+  ca.R = la.R;
   ca.recon_scale = recon_scale;
-  ca.vec4 = (reinterpret_cast<uintptr_t>(w.slab) % 16 == 0 && n_flat % 4 == 0 && off.w[FUNC0] % 4 == 0 && off.w[FUNC2] % 4 == 0) ? 1 : 0;
+  ca.vec4 = (reinterpret_cast<uintptr_t>(w.slab) % 16 == 0 && n_flat % 4 == 0 && off.w[FUNC2] % 4 == 0) ? 1 : 0;
   {
-    // forward + input-gradient + weight-gradient products of loc/func.0/func.2/func.4: 3 * 2 * 12352 flop per car
+    // the algorithm's forward + input-gradient + weight-gradient products of loc/func.0/func.2/func.4:
+    // 3 * 2 * 12352 flop per car (func.0's share is not executed per car here, see the kernel's header)
     ProfScope ps("vae_car_fwd_bwd_kernel", st, 6.0 * (8192 + 4096 + 32 + 32) * rows, 4.0 * (2.0 * rows + 64.0 * B));
     hipLaunchKernelGGL(vae_car_fwd_bwd_kernel, dim3(ncar), dim3(256), CAR_LDS_FLOATS * 4, st, ca);
     HHRL_TRY(launch_status("vae_car_fwd_bwd_kernel"));
@@ -1652,14 +1753,18 @@ static int vae_step_impl(float* params, float* grads, float* m, float* v, const 
   // per-car gradient slabs summed by extra workgroups of the per-lane backward launch, on CUs it leaves idle
   CarReduce cr;
   cr.slab = w.slab; cr.total = n_flat; cr.lo = car_lo; cr.hi = car_hi;
+  cr.hole_lo = f0_lo; cr.hole_hi = f0_hi;
+  cr.svec = w.aux + 192;
   cr.grads = grads; cr.params = adam ? params : nullptr; cr.m = m; cr.v = v;
   cr.k = adam ? *adam : AdamK();
   cr.n_car = ncar; cr.first_block = nlane; cr.n_blocks = 0;
-  if (nlane >= la.tiles && lane_threads == 512 && nlane < 256 && car_lo % 64 == 0) {
-    const long pairs = ((car_hi - car_lo + 63) / 64 + 1) / 2;
+  if (nlane >= la.tiles && lane_threads == 512 && nlane < 256 && car_lo % 64 == 0 && f0_lo % 64 == 0 && b0_off == f0_hi) {
+    const long pairs = ((f0_lo - car_lo + 63) / 64 + (car_hi - f0_hi + 63) / 64 + 2 + 1) / 2;
     cr.n_blocks = (int)(pairs < 256 - nlane ? pairs : 256 - nlane);
   }
-  const long skip_lo = cr.n_blocks > 0 ? car_lo : 0, skip_hi = cr.n_blocks > 0 ? ((car_hi + 63) / 64) * 64 : 0;
+  // 64-column blocks the reduction kernel leaves out: the ranges in front of and behind func.0's matrix
+  const bool co = cr.n_blocks > 0;
+  const long skip_lo = co ? car_lo : 0, skip_mid = co ? f0_lo : 0, skip_back = co ? f0_hi : 0, skip_hi = co ? ((car_hi + 63) / 64) * 64 : 0;
   {
     ProfScope ps("vae_lane_backward_kernel", st, 4.0 * lane_macs * B, 4.0 * B * (2.0 * N + g + 32));
     if (nlane >= la.tiles && lane_threads == 512)
@@ -1672,10 +1777,11 @@ static int vae_step_impl(float* params, float* grads, float* m, float* v, const 
   }
   {
     // reads every slab column once (per-car columns from ncar slabs, the others from nlane), writes the gradient
-    const double slab_floats = (cr.n_blocks > 0 ? 0.0 : (double)(car_hi - car_lo) * ncar) + (double)(n_flat - (car_hi - car_lo)) * nlane;
+    const double slab_floats = (cr.n_blocks > 0 ? 256.0 * ncar : (double)(car_hi - car_lo - 8192 + 128) * ncar) +
+                               (double)(n_flat - (car_hi - car_lo) + 4096) * nlane;
     ProfScope ps("vae_reduce_grads_kernel", st, 0.0, 4.0 * (slab_floats + n_flat * (adam ? 7.0 : 1.0)));
     hipLaunchKernelGGL(vae_reduce_grads_kernel, dim3(ceil_div(n_flat, 64)), dim3(256), 0, st, w.slab, n_flat, ncar, nlane,
-                       car_lo, car_hi, skip_lo, skip_hi, grads, w.loss_part, w.kl_part, loss, adam ? params : nullptr, m, v,
+                       car_lo, car_hi, f0_lo, b0_off, w.aux + 128, co ? w.aux + 192 : nullptr, skip_lo, skip_mid, skip_back, skip_hi, grads, w.loss_part, w.kl_part, loss, adam ? params : nullptr, m, v,
                        adam ? *adam : AdamK());
     HHRL_TRY(launch_status("vae_reduce_grads_kernel"));
   }
@@ -1723,7 +1829,7 @@ int hhrl_vae_encode(const float* params, const long* offsets, long n_flat, const
   EncArgs a;
   HHRL_TRY(lane_layers(a.g, params, offsets, n_flat, g, "vae_encode"));
   a.g.data = cars;
-  a.g.eps = nullptr; a.g.d2 = nullptr; a.g.act = nullptr; a.g.dpart = nullptr; a.g.slab = nullptr; a.g.kl_part = nullptr;
+  a.g.eps = nullptr; a.g.u = nullptr; a.g.aux = nullptr; a.g.act = nullptr; a.g.spart = nullptr; a.g.slab = nullptr; a.g.kl_part = nullptr;
   a.g.B = B; a.g.N = N; a.g.g = g; a.g.tiles = (B + 31) / 32;
   a.lane_start = lane_start;
   a.out = out;
