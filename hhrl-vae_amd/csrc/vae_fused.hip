@@ -61,33 +61,41 @@ struct CarArgs {
   const float* u;     // [B][128]
   const float* pvec;  // [128]
   const float *w0, *w2, *b2, *w4, *b4;
-  float* spart;       // [tiles * R][128] sum of df1 per traffic lane within a tile:
-                      // row tile*R + s belongs to traffic lane (tile*32)/N + s
+  float* spart;       // [tiles * R][128] sum of df1 per traffic lane within a tile of 16 cars:
+                      // row tile*R + s belongs to traffic lane (tile*16)/N + s
   float* slab;        // [gridDim.x][total]
   float* loss_part;   // [gridDim.x]
   Offsets off;
   long rows;          // B*N
-  int N, tiles, R;    // R = most traffic lanes a tile of 32 cars can touch
+  int N, tiles, R;    // tiles of CAR_TILE cars; R = most traffic lanes a tile can touch
   float recon_scale;
   int vec4;           // slab rows and the func.2 weight offset are 16-byte aligned
 };
 
+// A wave owns a tile of 16 cars; eight waves per workgroup, two per SIMD, so that one wave's element-wise
+// phases and LDS round trips run under the other's matrix instructions.
+constexpr int CAR_TILE = 16, CAR_WAVES = 8, CAR_THREADS = 64 * CAR_WAVES;
 constexpr int CAR_W2 = 0;                          // [32][129]
 constexpr int CAR_SMALL = CAR_W2 + 32 * 129;       // b2[32] w4[32] b4[1]
 constexpr int CAR_WAVE0 = CAR_SMALL + 96;
-constexpr int CAR_F1 = 0;                          // per wave: [32][129] f1, later df1
-constexpr int CAR_F2 = CAR_F1 + 32 * 129;          // [32][33]
-constexpr int CAR_ROW = CAR_F2 + 32 * 33;          // dpre[32] (+96 spare)
-constexpr int CAR_WAVE_FLOATS = CAR_ROW + 128;
-constexpr int CAR_LDS_FLOATS = CAR_WAVE0 + 4 * CAR_WAVE_FLOATS;
+constexpr int CAR_F1 = 0;                          // per wave: [16][129] f1, later df1
+constexpr int CAR_F2 = CAR_F1 + 16 * 129;          // [16][33]
+constexpr int CAR_ROW = CAR_F2 + 16 * 33;          // dpre[16] (+48 spare)
+constexpr int CAR_WAVE_FLOATS = CAR_ROW + 64;
+// the end of the kernel reuses the LDS: a buffer of CAR_Q1 floats per wave, then s | db0 | partial products
+constexpr int CAR_Q1 = 4420, CAR_FIN = CAR_WAVES * CAR_Q1, CAR_FIN_FLOATS = 256 + 16 * 64;
+constexpr int CAR_IMG_FLOATS = CAR_WAVE0 + CAR_WAVES * CAR_WAVE_FLOATS;
+constexpr int CAR_LDS_FLOATS = CAR_IMG_FLOATS > CAR_FIN + CAR_FIN_FLOATS ? CAR_IMG_FLOATS : CAR_FIN + CAR_FIN_FLOATS;
+static_assert(CAR_LDS_FLOATS * 4 <= 163840, "per-car kernel must fit the 160 KiB LDS");
 
-// most traffic lanes that 32 consecutive cars can belong to
-static inline int lanes_per_car_tile(int N) { const int v = 31 / N + 2; return v < 32 ? v : 32; }
+// most traffic lanes that CAR_TILE consecutive cars can belong to
+static inline int lanes_per_car_tile(int N) { const int v = (CAR_TILE - 1) / N + 2; return v < CAR_TILE ? v : CAR_TILE; }
 
-__global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
+__global__ __launch_bounds__(CAR_THREADS, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
+  const int r = lane & 31, h = lane >> 5;            // operand lanes of the 32x32 products (dW2)
+  const int j = lane & 15, q = lane >> 4;            // 16x16 blocks: column j, rows 4 q + reg
 
   HHRL_STAMP(0, 0);
   float* W2s = lds + CAR_W2;
@@ -99,57 +107,50 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
   float* f2i = wl + CAR_F2;
   float* dpre = wl + CAR_ROW;
 
-  // Inputs of a tile.  Lane r (both halves) holds car r; for the sixteen rows drow(i, h) of the accumulator
-  // layout a lane also holds their loc, and column 32 t + r of their traffic lane's U row.
-  float in_v, loc_i[16], ind[16];
+  // Inputs of a tile.  Lane j (all four groups q) holds car j; for the four rows 4 q + reg of the
+  // accumulator layout a lane also holds their loc, and column 16 blk + j of their traffic lane's U row.
+  float in_v, loc_i[4], ind[4];
   int in_b;
-  f32x16 f1[4];                                      // U rows on arrival, f1 after the activation
+  f32x4 f1[8];                                       // U rows on arrival, f1 after the activation
   auto fetch_tile = [&](int tile) {
-    const int row = tile * 32 + r;                                   // the host keeps the car count below 2^31
+    const int row = tile * CAR_TILE + j;                             // the host keeps the car count below 2^31
     const bool valid = tile < g.tiles && row < g.rows;
     const float2 lv = valid ? *reinterpret_cast<const float2*>(g.data + 2 * (long)row) : make_float2(0.f, 0.f);
     in_b = valid ? (int)((unsigned)row / (unsigned)g.N) : -1;
     // all exchanges first, then all loads from clamped addresses (no branch between them), so that the
     // round trips overlap.  Rows without a car read lane 0's row; their gradients are zero (dpre = 0).
-    int b_i[16];
+    int b_i[4], b_k[4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) b_i[i] = __shfl(in_b, drow(i, h), 64);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float* up = g.u + (long)max(b_i[i], 0) * 128 + r;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) f1[t][i] = up[32 * t];
+    for (int e = 0; e < 4; ++e) {
+      b_i[e] = __shfl(in_b, 4 * q + e, 64);
+      b_k[e] = __shfl(in_b, 4 * e + q, 64);
     }
-    // 0/1 operand of the per-lane sums: step k of the product takes car k + h, output row s = lane r
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float* up = g.u + (long)max(b_i[e], 0) * 128 + j;
+#pragma unroll
+      for (int blk = 0; blk < 8; ++blk) f1[blk][e] = up[16 * blk];
+    }
+    // 0/1 operand of the per-lane sums: step st of the product takes car 4 st + q, output row s = lane j
     const int b_first = __builtin_amdgcn_readfirstlane(in_b);
 #pragma unroll
-    for (int k = 0; k < 32; k += 2) {
-      const int b0 = __builtin_amdgcn_readlane(in_b, k), b1 = __builtin_amdgcn_readlane(in_b, k + 1);
-      const int bk = h ? b1 : b0;
-      ind[k >> 1] = (bk >= 0 && bk - b_first == r) ? 1.f : 0.f;
-    }
+    for (int e = 0; e < 4; ++e) ind[e] = (b_k[e] >= 0 && b_k[e] - b_first == j) ? 1.f : 0.f;
     in_v = lv.y;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) loc_i[i] = __shfl(lv.x, drow(i, h), 64);
+    for (int e = 0; e < 4; ++e) loc_i[e] = __shfl(lv.x, 4 * q + e, 64);
   };
 
-  float p_t[4];
-  float w0e[16];                                     // W0[16 og + k][32 + j] for the loc gradients at the end
+  float p_t[8];
   {
     // the matrix is requested first (the longest transfer), then the wave's tile; the narrow layers
     // travel in the same round trip
-    float4 v2[4];
-    request_w4<32, 128>(v2, g.w2, tid);
+    float4 v2[2];
+    request_w4<32, 128, 2, CAR_THREADS>(v2, g.w2, tid);
     const float p_b2 = g.b2[r], p_w4 = g.w4[r], p_b4 = g.b4[0];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) p_t[t] = g.pvec[32 * t + r];
-    fetch_tile(blockIdx.x * 4 + wave);
-    {
-      const int j = tid & 31, og = tid >> 5;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) w0e[k] = g.w0[(16 * og + k) * 64 + 32 + j];
-    }
-    commit_w4<32, 128>(W2s, 129, v2, tid);
+    for (int blk = 0; blk < 8; ++blk) p_t[blk] = g.pvec[16 * blk + j];
+    fetch_tile(blockIdx.x * CAR_WAVES + wave);
+    commit_w4<32, 128, 2, CAR_THREADS>(W2s, 129, v2, tid);
     if (tid < 32) {
       b2s[tid] = p_b2;
       w4s[tid] = p_w4;
@@ -161,7 +162,9 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
 
   // weight-gradient accumulators of func.2 and the column sums, kept across the wave's tiles
   f32x16 dW2[4];
-  float db0[4] = {0.f, 0.f, 0.f, 0.f}, sacc[4] = {0.f, 0.f, 0.f, 0.f};
+  float db0[8], sacc[8];
+#pragma unroll
+  for (int blk = 0; blk < 8; ++blk) db0[blk] = sacc[blk] = 0.f;
   float w4acc = 0.f, db2acc = 0.f, b4acc = 0.f, lossacc = 0.f;
 
   auto process_tile = [&](auto first_tag, int tile) {
@@ -173,53 +176,53 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
 
     // ---- forward: func.0 = ReLU(U[lane] + loc * p)
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int blk = 0; blk < 8; ++blk) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) f1[t][i] = fmaxf(fmaf(loc_i[i], p_t[t], f1[t][i]), 0.f);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) store_tile<129>(f1i, 32 * t, f1[t], lane);
+      for (int e = 0; e < 4; ++e) f1[blk][e] = fmaxf(fmaf(loc_i[e], p_t[blk], f1[blk][e]), 0.f);
+      store_block16<129>(f1i, 0, 16 * blk, f1[blk], lane);
+    }
     wave_sync();
     HHRL_STAMP(0, 3);
 
     // ---- forward: func.2 (128 -> 32, ReLU)
-    {
-      f32x16 f2[1];
-      f2[0] = splat(b2s[r]);
-      wave_mma<1, 128, 129, 1, 1, 129>(f2, f1i, W2s, lane);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) f2[0][i] = fmaxf(f2[0][i], 0.f);
-      store_tile<33>(f2i, 0, f2[0], lane);
+    for (int t = 0; t < 2; ++t) {
+      f32x4 c = wave_mma16<128, 129, 1, 1, 129>(f1i, W2s + 16 * t * 129, lane, b2s[16 * t + j]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) c[e] = fmaxf(c[e], 0.f);
+      store_block16<33>(f2i, 0, 16 * t, c, lane);
     }
     wave_sync();
     HHRL_STAMP(0, 4);
 
-    // ---- forward: func.4 (32 -> 1, sigmoid), squared error and its gradient per car
+    // ---- forward: func.4 (32 -> 1, sigmoid), squared error and its gradient per car (lane j, eight features per group q)
     {
       float s = 0.f;
 #pragma unroll
-      for (int n = 0; n < 16; ++n) s += w4s[16 * h + n] * f2i[r * 33 + 16 * h + n];
+      for (int n = 0; n < 8; ++n) s += w4s[8 * q + n] * f2i[j * 33 + 8 * q + n];
+      s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);
       s += b4s[0];
       const float out = 1.f / (1.f + expf(-s));
       const float d = out - v;
       float dp = 0.f;
       if (valid) {
-        if (h == 0) lossacc += g.recon_scale * d * d;
+        if (q == 0) lossacc += g.recon_scale * d * d;
         dp = 2.f * g.recon_scale * d * out * (1.f - out);
       }
-      if (h == 0) {
-        dpre[r] = dp;
+      if (q == 0) {
+        dpre[j] = dp;
         b4acc += dp;
       }
     }
     wave_sync();
     HHRL_STAMP(0, 5);
 
-    // ---- backward func.4 / ReLU of func.2: dW4, db2 and df2 (in place over the f2 image)
+    // ---- backward func.4 / ReLU of func.2: dW4, db2 and df2 (in place over the f2 image); lane: feature r, cars 8 h ..
     {
       const float w4n = w4s[r];
-#pragma unroll 4
-      for (int rr = 16 * h; rr < 16 * h + 16; ++rr) {
+#pragma unroll
+      for (int rr = 8 * h; rr < 8 * h + 8; ++rr) {
         const float fv = f2i[rr * 33 + r];
         const float dp = dpre[rr];
         w4acc += dp * fv;
@@ -231,32 +234,31 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
     wave_sync();
     HHRL_STAMP(0, 6);
 
-    // ---- backward func.2: dW2 += df2^T f1 ; df1 = (df2 W2) o relu'(f1)
+    // ---- backward func.2: dW2 += df2^T f1 (32x32 tiles over the 16 cars) ; df1 = (df2 W2) o relu'(f1)
     if (FIRST) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) dW2[t] = splat(0.f);
     }
-    wave_mma<4, 32, 1, 33, 129, 1>(dW2, f2i, f1i, lane);
-    f32x16 df1[4];
+    wave_mma<4, CAR_TILE, 1, 33, 129, 1>(dW2, f2i, f1i, lane);
+    f32x4 df1[8];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) df1[t] = splat(0.f);
-    wave_mma<4, 32, 33, 1, 129, 1>(df1, f2i, W2s, lane);
+    for (int blk = 0; blk < 8; ++blk) df1[blk] = wave_mma16<32, 33, 1, 129, 1>(f2i, W2s + 16 * blk, lane, 0.f);
     wave_sync();                           // all reads of the f1 image are done
     HHRL_STAMP(0, 7);
     // ---- ReLU mask of func.0, its column sums (db0, and s weighted by loc), df1 over the f1 image
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int blk = 0; blk < 8; ++blk) {
       float cs = 0.f, ss = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float dv = f1[t][i] > 0.f ? df1[t][i] : 0.f;
-        df1[t][i] = dv;
+      for (int e = 0; e < 4; ++e) {
+        const float dv = f1[blk][e] > 0.f ? df1[blk][e] : 0.f;
+        df1[blk][e] = dv;
         cs += dv;
-        ss = fmaf(dv, loc_i[i], ss);
+        ss = fmaf(dv, loc_i[e], ss);
       }
-      db0[t] += cs;
-      sacc[t] += ss;
-      store_tile<129>(f1i, 32 * t, df1[t], lane);
+      db0[blk] += cs;
+      sacc[blk] += ss;
+      store_block16<129>(f1i, 0, 16 * blk, df1[blk], lane);
     }
     wave_sync();
     HHRL_STAMP(0, 8);
@@ -265,23 +267,22 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
     //      P[s][col] = sum over the tile's cars of [lane of car == first lane of the tile + s] * df1[car][col]
     //      (exact: the indicator is 0 or 1, the cars of a lane add up in car order)
     {
-      f32x16 P[4];
+      f32x4 P[8];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) P[t] = splat(0.f);
+      for (int blk = 0; blk < 8; ++blk) P[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < 32; k += 2) {
-        const float a = ind[k >> 1];
+      for (int st = 0; st < 4; ++st) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-          P[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, f1i[(k + h) * 129 + 32 * t + r], P[t], 0, 0, 0);
+        for (int blk = 0; blk < 8; ++blk)
+          P[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(ind[st], f1i[(4 * st + q) * 129 + 16 * blk + j], P[blk], 0, 0, 0);
       }
       // every tile owns R rows; a tile's rows past its last traffic lane are zero and nobody reads them
-      float* dst = g.spart + (long)tile * g.R * 128 + r;
+      float* dst = g.spart + (long)tile * g.R * 128 + j;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        if (drow(i, h) < g.R) {
+      for (int e = 0; e < 4; ++e) {
+        if (4 * q + e < g.R) {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) dst[drow(i, h) * 128 + 32 * t] = P[t][i];
+          for (int blk = 0; blk < 8; ++blk) dst[(4 * q + e) * 128 + 16 * blk] = P[blk][e];
         }
       }
     }
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
     HHRL_STAMP(0, 9);
   };
   {
-    const int tile0 = blockIdx.x * 4 + wave, stride = gridDim.x * 4;
+    const int tile0 = blockIdx.x * CAR_WAVES + wave, stride = gridDim.x * CAR_WAVES;
     if (tile0 < g.tiles) {
       process_tile(std::true_type(), tile0);
       for (int tile = tile0 + stride; tile < g.tiles; tile += stride) process_tile(std::false_type(), tile);
@@ -299,39 +300,50 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
     }
   }
 
-  // ---- combine the two lane halves (they hold different rows of the same columns)
+  // ---- combine the lane groups that hold different rows of the same columns
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    db0[t] += __shfl_xor(db0[t], 32, 64);
-    sacc[t] += __shfl_xor(sacc[t], 32, 64);
+  for (int blk = 0; blk < 8; ++blk) {
+    db0[blk] += __shfl_xor(db0[blk], 16, 64);
+    db0[blk] += __shfl_xor(db0[blk], 32, 64);
+    sacc[blk] += __shfl_xor(sacc[blk], 16, 64);
+    sacc[blk] += __shfl_xor(sacc[blk], 32, 64);
   }
   w4acc += __shfl_xor(w4acc, 32, 64);
   db2acc += __shfl_xor(db2acc, 32, 64);
   b4acc = wave_sum(b4acc);
   lossacc = wave_sum(lossacc);
 
-  // ---- combine the four waves in LDS in a fixed order.  Every image is dead by now: each wave stores
-  //      its sums into a quarter buffer, all 256 threads then add the four quarters element-wise
-  //      ((w0 + w1) + (w2 + w3)) while writing the slab.
+  // ---- combine the eight waves in LDS in a fixed order.  Every image is dead by now: each wave stores
+  //      its sums into a buffer of its own, all threads then add the eight buffers element-wise
+  //      (((w0 + w1) + (w2 + w3)) + ((w4 + w5) + (w6 + w7))) while writing the slab.
   __syncthreads();
   HHRL_STAMP(0, 10);
+  // W0[8 og + k][32 + jj] for the loc gradients at the very end, requested now
+  float w0e[8];
+  {
+    const int jj = tid & 31, og = tid >> 5;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w0e[k] = g.w0[(8 * og + k) * 64 + 32 + jj];
+  }
   float* slab = g.slab + (long)blockIdx.x * g.off.total;
+  constexpr int Q1 = CAR_Q1;
   constexpr int B_W2 = 0, B_B0 = 4096, B_S = B_B0 + 128, B_B2 = B_S + 128, B_W4 = B_B2 + 32, B_B4 = B_W4 + 32;
-  constexpr int B_LOSS = B_B4 + 1, Q1 = 4420;
-  constexpr int FIN = 4 * Q1;                        // s[128] db0[128], then partial products [8][64]
-  static_assert(B_LOSS + 1 <= Q1 && Q1 % 4 == 0 && FIN + 256 + 512 <= CAR_LDS_FLOATS, "combine buffers must fit the workgroup's LDS");
+  constexpr int B_LOSS = B_B4 + 1;
+  static_assert(B_LOSS + 1 <= Q1 && Q1 % 4 == 0, "per-wave buffer layout");
   {
     float* mine = lds + wave * Q1;
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) mine[B_W2 + drow(i, h) * 128 + jt * 32 + r] = dW2[jt][i];
-    if (h == 0) {
+    if (q == 0) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        mine[B_B0 + t * 32 + r] = db0[t];
-        mine[B_S + t * 32 + r] = sacc[t];
+      for (int blk = 0; blk < 8; ++blk) {
+        mine[B_B0 + 16 * blk + j] = db0[blk];
+        mine[B_S + 16 * blk + j] = sacc[blk];
       }
+    }
+    if (h == 0) {
       mine[B_B2 + r] = db2acc;
       mine[B_W4 + r] = w4acc;
       if (r == 0) {
@@ -342,57 +354,62 @@ __global__ __launch_bounds__(256, 1) void vae_car_fwd_bwd_kernel(CarArgs g) {
   }
   __syncthreads();
   HHRL_STAMP(0, 11);
-  auto sum4 = [](const float4& a, const float4& b, const float4& c, const float4& d) {
-    return make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+  auto add4 = [](const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
+  auto all8 = [&](int i) {
+    return ((lds[i] + lds[Q1 + i]) + (lds[2 * Q1 + i] + lds[3 * Q1 + i])) +
+           ((lds[4 * Q1 + i] + lds[5 * Q1 + i]) + (lds[6 * Q1 + i] + lds[7 * Q1 + i]));
   };
-  auto all4 = [&](int i) { return (lds[i] + lds[Q1 + i]) + (lds[2 * Q1 + i] + lds[3 * Q1 + i]); };
   if (g.vec4) {                                      // 16-byte aligned slab and offsets (wave-uniform): four elements per access
-    const float4* q = reinterpret_cast<const float4*>(lds + B_W2);
+    const float4* qv = reinterpret_cast<const float4*>(lds + B_W2);
     float4* dst = reinterpret_cast<float4*>(slab + g.off.w[FUNC2]);
+    constexpr int S4 = Q1 / 4;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = u * 256 + tid;
-      dst[i] = sum4(q[i], q[Q1 / 4 + i], q[2 * (Q1 / 4) + i], q[3 * (Q1 / 4) + i]);
+    for (int u = 0; u < 1024 / CAR_THREADS; ++u) {
+      const int i = u * CAR_THREADS + tid;
+      dst[i] = add4(add4(add4(qv[i], qv[S4 + i]), add4(qv[2 * S4 + i], qv[3 * S4 + i])),
+                    add4(add4(qv[4 * S4 + i], qv[5 * S4 + i]), add4(qv[6 * S4 + i], qv[7 * S4 + i])));
     }
   } else {
-    for (int i = tid; i < 4096; i += 256) slab[g.off.w[FUNC2] + i] = all4(B_W2 + i);
+    for (int i = tid; i < 4096; i += CAR_THREADS) slab[g.off.w[FUNC2] + i] = all8(B_W2 + i);
   }
-  float* fin = lds + FIN;
+  float* fin = lds + CAR_FIN;
   if (tid < 128) {
-    const float sv = all4(B_S + tid);
+    const float sv = all8(B_S + tid);
     fin[tid] = sv;
     slab[g.off.w[FUNC0] + tid * 64 + 32] = sv;       // s[o] travels in the first position of row o that no sum uses
-  } else {
-    const float dv = all4(B_B0 + tid - 128);
+  } else if (tid < 256) {
+    const float dv = all8(B_B0 + tid - 128);
     fin[tid] = dv;
     slab[g.off.b[FUNC0] + tid - 128] = dv;
-  }
-  if (tid < 32) {
-    slab[g.off.b[FUNC2] + tid] = all4(B_B2 + tid);
-    slab[g.off.w[FUNC4] + tid] = all4(B_W4 + tid);
-  }
-  if (tid == 0) {
-    slab[g.off.b[FUNC4]] = all4(B_B4);
-    g.loss_part[blockIdx.x] = all4(B_LOSS);
+  } else if (tid < 288) {
+    slab[g.off.b[FUNC2] + tid - 256] = all8(B_B2 + tid - 256);
+  } else if (tid < 320) {
+    slab[g.off.w[FUNC4] + tid - 288] = all8(B_W4 + tid - 288);
+  } else if (tid == 320) {
+    slab[g.off.b[FUNC4]] = all8(B_B4);
+  } else if (tid == 321) {
+    g.loss_part[blockIdx.x] = all8(B_LOSS);
   }
   __syncthreads();
-  // ---- loc embedding: dwloc[j] = sum_o s[o] W0[o][32 + j], dbloc[j] = sum_o db0[o] W0[o][32 + j]
-  //      (this workgroup's share; eight groups of sixteen o each, combined in a fixed order)
+  // ---- loc embedding: dwloc[jj] = sum_o s[o] W0[o][32 + jj], dbloc[jj] = sum_o db0[o] W0[o][32 + jj]
+  //      (this workgroup's share; sixteen groups of eight o each, combined in a fixed order)
   {
-    const int j = tid & 31, og = tid >> 5;
+    const int jj = tid & 31, og = tid >> 5;
     float pw = 0.f, pb = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      pw = fmaf(fin[16 * og + k], w0e[k], pw);
-      pb = fmaf(fin[128 + 16 * og + k], w0e[k], pb);
+    for (int k = 0; k < 8; ++k) {
+      pw = fmaf(fin[8 * og + k], w0e[k], pw);
+      pb = fmaf(fin[128 + 8 * og + k], w0e[k], pb);
     }
-    fin[256 + og * 64 + j] = pw;
-    fin[256 + og * 64 + 32 + j] = pb;
+    fin[256 + og * 64 + jj] = pw;
+    fin[256 + og * 64 + 32 + jj] = pb;
   }
   __syncthreads();
   if (tid < 64) {
     const float* pp = fin + 256 + tid;
-    const float sum = ((pp[0] + pp[64]) + (pp[128] + pp[192])) + ((pp[256] + pp[320]) + (pp[384] + pp[448]));
+    float sum = 0.f;
+#pragma unroll
+    for (int og = 0; og < 16; og += 4) sum += (pp[og * 64] + pp[(og + 1) * 64]) + (pp[(og + 2) * 64] + pp[(og + 3) * 64]);
     slab[(tid < 32 ? g.off.w[LOC] + tid : g.off.b[LOC] + tid - 32)] = sum;
   }
   HHRL_STAMP(0, 12);
@@ -1256,7 +1273,7 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
     }
     // S of a traffic lane = sum of the per-(car tile, lane) rows of the car tiles its cars span, in tile
     // order.  A thread owns one lane and CPT columns of it.  The first two tiles (all there are when
-    // N <= 33) are read from clamped addresses without a branch, so the round trips of a thread overlap;
+    // N <= 17) are read from clamped addresses without a branch, so the round trips of a thread overlap;
     // longer lanes loop over the rest.
     constexpr int TPR = NT / 32, CPT = 128 / TPR;        // threads per lane row, columns per thread
     float4 sv[CPT / 4];
@@ -1265,10 +1282,10 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
       const unsigned n = (unsigned)g.N, R = (unsigned)g.R;
       const int b = row0 + s_row;
       const unsigned lo = (unsigned)b * n;
-      const unsigned t0 = lo >> 5, t1 = (lo + n - 1) >> 5;
+      const unsigned t0 = lo / CAR_TILE, t1 = (lo + n - 1) / CAR_TILE;
       const bool ok0 = b < g.B, ok1 = ok0 && t1 > t0;
-      const long a0 = ((long)t0 * R + ((unsigned)b - (t0 * 32u) / n)) * 128;
-      const long a1 = ((long)(t0 + 1) * R + ((unsigned)b - ((t0 + 1) * 32u) / n)) * 128;
+      const long a0 = ((long)t0 * R + ((unsigned)b - (t0 * CAR_TILE) / n)) * 128;
+      const long a1 = ((long)(t0 + 1) * R + ((unsigned)b - ((t0 + 1) * CAR_TILE) / n)) * 128;
       const float4* q0 = reinterpret_cast<const float4*>(g.spart + (ok0 ? a0 : 0) + s_col);
       const float4* q1 = reinterpret_cast<const float4*>(g.spart + (ok1 ? a1 : 0) + s_col);
       float4 p0[CPT / 4], p1[CPT / 4];
@@ -1283,7 +1300,7 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
         if (ok1) { sum.x += p1[u].x; sum.y += p1[u].y; sum.z += p1[u].z; sum.w += p1[u].w; }
         if (ok1 && t1 > t0 + 1) {
           for (unsigned t = t0 + 2; t <= t1; ++t) {
-            const float4 e = *reinterpret_cast<const float4*>(g.spart + ((long)t * R + ((unsigned)b - (t * 32u) / n)) * 128 + s_col + 4 * u * TPR);
+            const float4 e = *reinterpret_cast<const float4*>(g.spart + ((long)t * R + ((unsigned)b - (t * CAR_TILE) / n)) * 128 + s_col + 4 * u * TPR);
             sum.x += e.x; sum.y += e.y; sum.z += e.z; sum.w += e.w;
           }
         }
@@ -1601,8 +1618,8 @@ struct Ws {
 static long a64(long n) { return (n + 63) & ~63L; }
 
 static int grid_car(long rows) {
-  const long tiles = (rows + 31) / 32;
-  long gsz = (tiles + 3) / 4;
+  const long tiles = (rows + CAR_TILE - 1) / CAR_TILE;
+  long gsz = (tiles + CAR_WAVES - 1) / CAR_WAVES;
   if (gsz > 256) gsz = 256;
   return (int)(gsz < 1 ? 1 : gsz);
 }
@@ -1618,7 +1635,7 @@ static Ws carve(float* ws, int B, int N, int g, long n_flat) {
   auto take = [&](long n) { float* p = ws ? ws + off : nullptr; off += a64(n); return p; };
   w.u = take((long)B * 128);
   w.aux = take(320);   // p[128] | wloc[32] bloc[32] as the step found them | s[128]
-  w.spart = take(((long)B * N + 31) / 32 * lanes_per_car_tile(N) * 128);
+  w.spart = take(((long)B * N + CAR_TILE - 1) / CAR_TILE * lanes_per_car_tile(N) * 128);
   w.act = take((long)((B + 31) / 32) * LN_ACT_FLOATS);
   w.loss_part = take(256);
   w.kl_part = take(256);
@@ -1739,7 +1756,7 @@ static int vae_step_impl(float* params, float* grads, float* m, float* v, const 
   ca.off = off;
   ca.rows = rows;
   ca.N = N;
-  ca.tiles = (int)((rows + 31) / 32);
+  ca.tiles = (int)((rows + CAR_TILE - 1) / CAR_TILE);
   ca.R = la.R;
   ca.recon_scale = recon_scale;
   ca.vec4 = (reinterpret_cast<uintptr_t>(w.slab) % 16 == 0 && n_flat % 4 == 0 && off.w[FUNC2] % 4 == 0) ? 1 : 0;
@@ -1747,7 +1764,7 @@ static int vae_step_impl(float* params, float* grads, float* m, float* v, const 
     // the algorithm's forward + input-gradient + weight-gradient products of loc/func.0/func.2/func.4:
     // 3 * 2 * 12352 flop per car (func.0's share is not executed per car here, see the kernel's header)
     ProfScope ps("vae_car_fwd_bwd_kernel", st, 6.0 * (8192 + 4096 + 32 + 32) * rows, 4.0 * (2.0 * rows + 64.0 * B));
-    hipLaunchKernelGGL(vae_car_fwd_bwd_kernel, dim3(ncar), dim3(256), CAR_LDS_FLOATS * 4, st, ca);
+    hipLaunchKernelGGL(vae_car_fwd_bwd_kernel, dim3(ncar), dim3(CAR_THREADS), CAR_LDS_FLOATS * 4, st, ca);
     HHRL_TRY(launch_status("vae_car_fwd_bwd_kernel"));
   }
   // per-car gradient slabs summed by extra workgroups of the per-lane backward launch, on CUs it leaves idle
