@@ -435,6 +435,8 @@ struct LaneArgs {
   float* u;            // [B][128] forward output: func.0 pre-activation of the lane's cars without the position term
   float* aux;          // forward output: p[128] = W0[:, 32:] wloc, then copies of wloc[32] and bloc[32]
   float* act;          // [tiles][LN_ACT_FLOATS] activation images: written by the forward, read by the backward kernel
+  float* wimg;         // [LN_WIMG_FLOATS] the weight and bias images exactly as they lie in LDS: written by the forward
+                       // kernel's first workgroup, copied verbatim by the backward kernel
   const float* spart;  // [car tiles * R][128] backward input: df1 summed per (car tile, traffic lane in it)
   float* slab;
   float* kl_part;      // [gridDim.x]
@@ -453,6 +455,8 @@ constexpr int LW_DEC2 = LW_DEC0 + 128 * 17;       // [32][129]
 constexpr int LW_BIAS = LW_DEC2 + 32 * 129;       // phi2[32] rho0[128] rho2[64] head[32] dec0[128] dec2[32]
 constexpr int LB_PHI2 = 0, LB_RHO0 = 32, LB_RHO2 = 160, LB_HEAD = 224, LB_DEC0 = 256, LB_DEC2 = 384, LB_END = 416;
 constexpr int LB_Q = LB_END, LB_ALL = LB_Q + 128; // q[128] = b0 + W0[:, 32:] bloc (forward kernel only)
+constexpr int LN_WIMG_FLOATS = LW_BIAS + LB_END;  // every weight image and the staged biases, contiguous from 0
+static_assert(LN_WIMG_FLOATS % 4 == 0, "the weight images are copied 16 bytes at a time");
 constexpr int LI_H1 = LW_BIAS + LB_ALL;           // [32][33]  summed hidden of phi (16 columns used)
 constexpr int LI_POOL = LI_H1 + 32 * 33;          // [32][33]
 constexpr int LI_R1 = LI_POOL + 32 * 33;          // [32][129]
@@ -622,8 +626,9 @@ struct ActRange {
   static_assert(LO % 4 == 0 && HI % 4 == 0, "image boundaries are multiples of 4 floats");
   static constexpr int V4 = (HI - LO) / 4, STEPS = (V4 + NT - 1) / NT;
   float4 v[STEPS];
-  __device__ __forceinline__ void request(const float* act_tile, int tid) {
-    const float4* src = reinterpret_cast<const float4*>(act_tile + (LO - LI_H1));
+  __device__ __forceinline__ void request(const float* act_tile, int tid) { request_from(act_tile + (LO - LI_H1), tid); }
+  __device__ __forceinline__ void request_from(const float* at_lo, int tid) {   // at_lo: global address of element LO
+    const float4* src = reinterpret_cast<const float4*>(at_lo);
 #pragma unroll
     for (int u = 0; u < STEPS; ++u) {
       const int i4 = u * NT + tid;
@@ -711,6 +716,16 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_forward_kernel(LaneArgs g) {
   if (blockIdx.x == 0 && tid < 64) g.aux[128 + tid] = tid < 32 ? g.w[LOC][tid] : g.b[LOC][tid - 32];
   __syncthreads();
   HHRL_STAMP(1, 1);
+  // The weight and bias images as they lie in LDS (the same in every workgroup), for the backward kernel,
+  // which then copies 16 bytes per instruction instead of placing rows, padding and zero fill again.
+  // The workgroups share the copy (one store per thread of the first few at the usual sizes), issued here so
+  // that it completes under the first phase.
+  {
+    const float4* src = reinterpret_cast<const float4*>(lds);
+    float4* dst = reinterpret_cast<float4*>(g.wimg);
+    for (int i4 = blockIdx.x * NT + tid; i4 < LN_WIMG_FLOATS / 4; i4 += gridDim.x * NT) dst[i4] = src[i4];
+  }
+
   for (int tile = blockIdx.x; tile < g.tiles; tile += gridDim.x) {
     const int row0 = tile * 32;
     const bool first = tile == (int)blockIdx.x;
@@ -1251,19 +1266,14 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
     const int row0 = tile * 32;
     const bool first = SINGLE || tile == (int)blockIdx.x;
     // ---- request everything the tile needs in the order of use
-    RegsB<NT> rB;
-    RegsD<NT> rD;
-    RegsR<NT> rR;
-    RegsP<NT> rP;
+    ActRange<0, LN_WIMG_FLOATS, NT> wimg;   // all weight images and biases, as the forward kernel left them
+    float cars_r[1024 / NT];
     ActRange<LI_ML, LI_D2, NT> actD;  // mean|logvar, z, d1
     ActRange<LI_R1, LI_ML, NT> actR;  // r1, r2
     ActRange<LI_H1, LI_R1, NT> actP;  // h1, pooled
     const float* act_tile = g.act + (long)tile * LN_ACT_FLOATS;
     actD.request(act_tile, tid);
-    if (first) {
-      request_bias(rB, g, tid);
-      request_D(rD, g, tid);
-    }
+    if (first) wimg.request_from(g.wimg, tid);
     // the noise of the tile's logvar columns, for the latent phase: elements tid + 256 u of [32][32]
     float eps_r[1024 / NT];
 #pragma unroll
@@ -1276,35 +1286,24 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
     // N <= 17) are read from clamped addresses without a branch, so the round trips of a thread overlap;
     // longer lanes loop over the rest.
     constexpr int TPR = NT / 32, CPT = 128 / TPR;        // threads per lane row, columns per thread
-    float4 sv[CPT / 4];
+    // The rows are only requested here; they are added up after every other request of the tile has been
+    // issued, so that the tile costs one memory round trip and not two.
     const int s_row = tid / TPR, s_col = 4 * (tid % TPR);
+    const unsigned s_n = (unsigned)g.N, s_R = (unsigned)g.R;
+    const int s_b = row0 + s_row;
+    const unsigned s_lo = (unsigned)s_b * s_n;
+    const unsigned s_t0 = s_lo / CAR_TILE, s_t1 = (s_lo + s_n - 1) / CAR_TILE;
+    const bool ok0 = s_b < g.B, ok1 = ok0 && s_t1 > s_t0;
+    float4 p0[CPT / 4], p1[CPT / 4];
     {
-      const unsigned n = (unsigned)g.N, R = (unsigned)g.R;
-      const int b = row0 + s_row;
-      const unsigned lo = (unsigned)b * n;
-      const unsigned t0 = lo / CAR_TILE, t1 = (lo + n - 1) / CAR_TILE;
-      const bool ok0 = b < g.B, ok1 = ok0 && t1 > t0;
-      const long a0 = ((long)t0 * R + ((unsigned)b - (t0 * CAR_TILE) / n)) * 128;
-      const long a1 = ((long)(t0 + 1) * R + ((unsigned)b - ((t0 + 1) * CAR_TILE) / n)) * 128;
+      const long a0 = ((long)s_t0 * s_R + ((unsigned)s_b - (s_t0 * CAR_TILE) / s_n)) * 128;
+      const long a1 = ((long)(s_t0 + 1) * s_R + ((unsigned)s_b - ((s_t0 + 1) * CAR_TILE) / s_n)) * 128;
       const float4* q0 = reinterpret_cast<const float4*>(g.spart + (ok0 ? a0 : 0) + s_col);
       const float4* q1 = reinterpret_cast<const float4*>(g.spart + (ok1 ? a1 : 0) + s_col);
-      float4 p0[CPT / 4], p1[CPT / 4];
 #pragma unroll
       for (int u = 0; u < CPT / 4; ++u) {
         p0[u] = q0[u * TPR];
         p1[u] = q1[u * TPR];
-      }
-#pragma unroll
-      for (int u = 0; u < CPT / 4; ++u) {
-        float4 sum = ok0 ? p0[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok1) { sum.x += p1[u].x; sum.y += p1[u].y; sum.z += p1[u].z; sum.w += p1[u].w; }
-        if (ok1 && t1 > t0 + 1) {
-          for (unsigned t = t0 + 2; t <= t1; ++t) {
-            const float4 e = *reinterpret_cast<const float4*>(g.spart + ((long)t * R + ((unsigned)b - (t * CAR_TILE) / n)) * 128 + s_col + 4 * u * TPR);
-            sum.x += e.x; sum.y += e.y; sum.z += e.z; sum.w += e.w;
-          }
-        }
-        sv[u] = sum;
       }
     }
     // func.0's columns for d2 as the B operand of dd2 = S A (16x16 blocks, step s takes k = 4 s + lane / 16)
@@ -1320,24 +1319,27 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
     ActRange<LI_D2, LI_DML, NT> actO;   // d2
     actO.request(act_tile, tid);
     actR.request(act_tile, tid);
-    if (first) request_R(rR, g, tid);
     actP.request(act_tile, tid);
-    if (first) request_P(rP, g, row0, tid); else request_cars<NT>(rP.cars, g, row0, tid);
+    request_cars<NT>(cars_r, g, row0, tid);
     // ---- and write it to LDS (S takes the slot of r1 until it has been used; r1 and r2 wait in registers)
 #pragma unroll
     for (int u = 0; u < CPT / 4; ++u) {
+      float4 sum = ok0 ? p0[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok1) { sum.x += p1[u].x; sum.y += p1[u].y; sum.z += p1[u].z; sum.w += p1[u].w; }
+      if (ok1 && s_t1 > s_t0 + 1) {
+        for (unsigned t = s_t0 + 2; t <= s_t1; ++t) {
+          const float4 e = *reinterpret_cast<const float4*>(g.spart + ((long)t * s_R + ((unsigned)s_b - (t * CAR_TILE) / s_n)) * 128 + s_col + 4 * u * TPR);
+          sum.x += e.x; sum.y += e.y; sum.z += e.z; sum.w += e.w;
+        }
+      }
       float* q = Ir1 + s_row * 129 + s_col + 4 * u * TPR;
-      q[0] = sv[u].x; q[1] = sv[u].y; q[2] = sv[u].z; q[3] = sv[u].w;
+      q[0] = sum.x; q[1] = sum.y; q[2] = sum.z; q[3] = sum.w;
     }
     actO.commit_at(Itmp, tid);
     actD.commit(lds, tid);
-    if (first) {
-      commit_bias(lds, rB, tid);
-      commit_D(lds, rD, g, tid);
-    }
-    if (first) commit_R(lds, rR, g, tid);
+    if (first) wimg.commit(lds, tid);
     actP.commit(lds, tid);
-    if (first) commit_P(lds, rP, g, tid); else commit_cars<NT>(lds, rP.cars, g, tid);
+    commit_cars<NT>(lds, cars_r, g, tid);
     __syncthreads();
     HHRL_STAMP(2, 1);
     // ---- func.0, the part shared by a lane's cars: dd2 = S A (16x16 blocks), dA[128][32] += S^T d2 (row tile `wave`)
@@ -1611,7 +1613,7 @@ __global__ __launch_bounds__(256) void vae_reduce_grads_kernel(const float* __re
 }
 
 struct Ws {
-  float *u, *aux, *spart, *act, *loss_part, *kl_part, *slab;
+  float *u, *aux, *spart, *act, *wimg, *loss_part, *kl_part, *slab;
   long total;
 };
 
@@ -1637,6 +1639,7 @@ static Ws carve(float* ws, int B, int N, int g, long n_flat) {
   w.aux = take(320);   // p[128] | wloc[32] bloc[32] as the step found them | s[128]
   w.spart = take(((long)B * N + CAR_TILE - 1) / CAR_TILE * lanes_per_car_tile(N) * 128);
   w.act = take((long)((B + 31) / 32) * LN_ACT_FLOATS);
+  w.wimg = take(LN_WIMG_FLOATS);
   w.loss_part = take(256);
   w.kl_part = take(256);
   const int ns = grid_car((long)B * N) > grid_lane(B) ? grid_car((long)B * N) : grid_lane(B);
@@ -1727,6 +1730,7 @@ static int vae_step_impl(float* params, float* grads, float* m, float* v, const 
   la.aux = w.aux;
   la.spart = w.spart;
   la.act = w.act;
+  la.wimg = w.wimg;
   la.slab = w.slab;
   la.kl_part = w.kl_part;
   la.off = off;
@@ -1846,7 +1850,7 @@ int hhrl_vae_encode(const float* params, const long* offsets, long n_flat, const
   EncArgs a;
   HHRL_TRY(lane_layers(a.g, params, offsets, n_flat, g, "vae_encode"));
   a.g.data = cars;
-  a.g.eps = nullptr; a.g.u = nullptr; a.g.aux = nullptr; a.g.act = nullptr; a.g.spart = nullptr; a.g.slab = nullptr; a.g.kl_part = nullptr;
+  a.g.eps = nullptr; a.g.u = nullptr; a.g.aux = nullptr; a.g.act = nullptr; a.g.wimg = nullptr; a.g.spart = nullptr; a.g.slab = nullptr; a.g.kl_part = nullptr;
   a.g.B = B; a.g.N = N; a.g.g = g; a.g.tiles = (B + 31) / 32;
   a.lane_start = lane_start;
   a.out = out;
