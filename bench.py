@@ -36,6 +36,18 @@ def vae_flops_per_lane(N: int, g: int) -> float:
     return 6.0 * (12896.0 * N + 16384.0 + 256.0 * g)
 
 
+def vae_executed_flops_per_lane(N: int, g: int) -> float:
+    """Matrix-core FLOPs the fused kernels execute per lane-sample.  The first
+    decoder layer over [d2 of the lane | loc embedding] is factored: per lane
+    U = d2 A^T, dd2 = S A, dA = S^T d2 (3 x 4096 MACs) instead of 3 x 8192 per
+    car; per car func.2 (3 x 4096 MACs) and the per-lane sums of df1 on the
+    matrix core (16 x 128 MACs per car of a 16-car tile).  phi.0, loc, func.4
+    and the position term of func.0 are element-wise."""
+    lane = 3.0 * (512 + 4096 + 8192 + 128.0 * g + 128.0 * g + 4096) + 3.0 * 4096
+    car = 3.0 * 4096 + 16.0 * 128
+    return 2.0 * (lane + car * N)
+
+
 def synth_lanes(B: int, N: int, seed: int) -> np.ndarray:
     rs = np.random.RandomState(seed)
     x = rs.uniform(0.0, 1.0, size=(B, N, 1))
@@ -277,6 +289,15 @@ def main() -> None:
             roof["traffic"] = tr["bytes"]
             roof["traffic_unit"] = "bytes per launch"
             roof["traffic_source"] = tr["source"]
+        # the same kernel priced by the matrix-core FLOPs it executes (see vae_executed_flops_per_lane)
+        lane_macs = 512 + 4096 + 8192 + 128.0 * g + 128.0 * g + 4096
+        executed = {"vae_car_fwd_bwd_kernel": 2.0 * (3 * 4096 + 16 * 128) * B * N,
+                    "vae_lane_forward_kernel": 2.0 * (lane_macs + 4096) * B,
+                    "vae_lane_backward_kernel": 2.0 * (2 * lane_macs + 2 * 4096) * B}.get(dom_name)
+        if mfma_bound and executed is not None:
+            ex = executed * dom["launches"] / (dom["ms"] * 1e-3) / 1e12
+            roof["executed"] = ex
+            roof["executed_frac"] = ex / PEAK_FP32_MATRIX_TFLOPS
         roof["avg_launch_us"] = 1e3 * dom["ms"] / max(dom["launches"], 1)
         roof["launches_per_step"] = dom["launches"] / prof_steps
         step_alg_tflops = vae_flops_per_lane(N, g) * B / (dt / args.steps) / 1e12
@@ -291,6 +312,8 @@ def main() -> None:
             "value_with_h2d_per_step": world * B * args.steps / dt_h2d,
             "step_algorithmic_tflops": step_alg_tflops,
             "step_frac_of_fp32_matrix_peak": step_alg_tflops / PEAK_FP32_MATRIX_TFLOPS,
+            "step_executed_matrix_tflops": vae_executed_flops_per_lane(N, g) * B / (dt / args.steps) / 1e12,
+            "executed_over_algorithmic_flops": vae_executed_flops_per_lane(N, g) / vae_flops_per_lane(N, g),
             "gpu_kernel_ms_per_step": gpu_ms_per_step,
             "kernels": {k: {"launches_per_step": v["launches"] / prof_steps, "ms_per_step": v["ms_per_step"]}
                         for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])},

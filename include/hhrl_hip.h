@@ -140,10 +140,13 @@ int hhrl_vae_latent_grad(const float* dz, const float* ml, const float* eps, flo
  *   grads is OVERWRITTEN with dL/dparams (fixed-order reduction: the same
  *   inputs give the same bits), *loss with recon_scale*sum(err^2) + KL;
  *   ws: hhrl_vae_workspace_floats(B,N,g,n_flat) floats, zero-filled once by the
- *   caller and then left to the library.
+ *   caller and then left to the library;
+ *   params and ws 16-byte aligned, every weight offset a multiple of 4 floats.
  * Four launches: per-lane forward, per-car forward+backward, per-lane
  * backward, slab reduction; all matrix products on fp32 MFMA with LDS-resident
- * weights. */
+ * weights.  func.0 (algorithm.py:61-70) over [d2 of the lane | loc embedding] is
+ * evaluated in factored form: its d2 half once per lane, its loc half as a
+ * rank-two term; same sums, another order. */
 long hhrl_vae_workspace_floats(int B, int N, int g, long n_flat);
 int hhrl_vae_train_step(const float* params, float* grads, const long* offsets, long n_flat,
                         const float* data, const float* eps, int B, int N, int g,
