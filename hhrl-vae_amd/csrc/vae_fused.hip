@@ -701,18 +701,6 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_forward_kernel(LaneArgs g) {
   commit_P(lds, rP, g, tid);
   commit_R(lds, rR, g, tid);
   commit_D(lds, rD, g, tid);
-  if (o_pq >= 0) {
-    float pv = 0.f, qv = b0o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float* wl4 = g.w[LOC] + 4 * e;
-      const float* bl4 = g.b[LOC] + 4 * e;
-      pv += w0e[e].x * wl4[0] + w0e[e].y * wl4[1] + w0e[e].z * wl4[2] + w0e[e].w * wl4[3];
-      qv += w0e[e].x * bl4[0] + w0e[e].y * bl4[1] + w0e[e].z * bl4[2] + w0e[e].w * bl4[3];
-    }
-    bs[LB_Q + o_pq] = qv;
-    if (blockIdx.x == 0) g.aux[o_pq] = pv;
-  }
   if (blockIdx.x == 0 && tid < 64) g.aux[128 + tid] = tid < 32 ? g.w[LOC][tid] : g.b[LOC][tid - 32];
   __syncthreads();
   HHRL_STAMP(1, 1);
@@ -774,6 +762,20 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_forward_kernel(LaneArgs g) {
     }
     __syncthreads();
     HHRL_STAMP(1, 5);
+    // p and q (first tile only), by threads that have nothing to do in the matrix phases when helper
+    // waves exist; q is first read after four more barriers
+    if (first && o_pq >= 0) {
+      float pv = 0.f, qv = b0o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float* wl4 = g.w[LOC] + 4 * e;
+        const float* bl4 = g.b[LOC] + 4 * e;
+        pv += w0e[e].x * wl4[0] + w0e[e].y * wl4[1] + w0e[e].z * wl4[2] + w0e[e].w * wl4[3];
+        qv += w0e[e].x * bl4[0] + w0e[e].y * bl4[1] + w0e[e].z * bl4[2] + w0e[e].w * bl4[3];
+      }
+      bs[LB_Q + o_pq] = qv;
+      if (blockIdx.x == 0) g.aux[o_pq] = pv;
+    }
     // ---- rho.2 (128 -> 64): two 16x16 blocks per wave
     if (mat) {
 #pragma unroll
