@@ -1,22 +1,25 @@
 // Fused DeepSets-VAE training step for gfx950: four launches per step.
 //
 //   vae_lane_forward   per traffic lane: phi (per car, pooled), rho, heads,
-//                      reparameterisation, latent branch of the decoder
-//   vae_car_fwd_bwd    per car: loc embedding, func.0/2/4, squared error, and
-//                      the whole backward of those layers (85 % of the FLOPs)
-//   vae_lane_backward  per traffic lane: backward of everything in the first
-//                      kernel (from its saved activations), KL gradient included
+//                      reparameterisation, latent branch of the decoder, and the
+//                      per-lane half of func.0 (see the per-car kernel's header)
+//   vae_car_fwd_bwd    per car: position term of func.0, func.2/4, squared error,
+//                      the backward of those layers, df1 summed per traffic lane
+//   vae_lane_backward  per traffic lane: the per-lane half of func.0's backward, then
+//                      the backward of everything in the first kernel (from its saved
+//                      activations), KL gradient included
 //   vae_reduce_grads   fixed-order sum of the per-workgroup gradient slabs
 //
-// Every matrix product runs on v_mfma_f32_32x32x2_f32 with BOTH operands read
-// from LDS "images": activations as [row][feature] with an odd row stride,
-// weights as [out][in] with an odd row stride.  With those strides the three
-// products of a layer (forward, input gradient, weight gradient) all read
-// their operands conflict-free from the same images, and an accumulator tile
-// (rows on registers, columns on lanes) is written back conflict-free.
-// Weight-gradient tiles stay in accumulator registers across a workgroup's
-// tiles and are written once, to that workgroup's slab; the gradient at the decoder
-// output crosses tile boundaries as one row per (car tile, traffic lane), summed in tile order: no atomics.
+// Every matrix product runs on the f32 matrix instructions (32x32x2, and 16x16x4
+// for thin outputs) with operands read from LDS "images": activations as
+// [row][feature] with an odd row stride, weights as [out][in] with an odd row
+// stride.  With those strides the three products of a layer (forward, input
+// gradient, weight gradient) all read their operands conflict-free from the same
+// images, and an accumulator tile (rows on registers, columns on lanes) is
+// written back conflict-free.  Weight-gradient tiles stay in accumulator
+// registers across a workgroup's tiles and are written once, to that workgroup's
+// slab; what crosses tile boundaries (the sums of df1 per traffic lane) travels as
+// one row per (car tile, traffic lane), added up in tile order: no atomics.
 #include "common.h"
 #include "mfma_tiles.h"
 
@@ -475,14 +478,6 @@ constexpr int LN_ACT_FLOATS = LI_DML - LI_H1;     // h1 | pooled | r1 | r2 | mea
 static_assert(LI_H1 % 4 == 0 && LN_ACT_FLOATS % 4 == 0, "activation images are copied 16 bytes at a time");
 constexpr int ACT_V4 = LN_ACT_FLOATS / 4;
 
-template <int NT = 256>
-__device__ __forceinline__ void store_rows32(const float* img, float* dst, int row0, int B, int tid) {
-#pragma unroll
-  for (int u = 0; u < 1024 / NT; ++u) {
-    const int idx = u * NT + tid, rr = idx >> 5, c = idx & 31;
-    if (row0 + rr < B) dst[(long)(row0 + rr) * 32 + c] = img[rr * 33 + c];
-  }
-}
 __device__ __forceinline__ float colsum32(const float* img, int ld, int col) {
   float s0 = 0.f, s1 = 0.f;
 #pragma unroll

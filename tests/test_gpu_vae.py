@@ -163,7 +163,8 @@ def test_vae_full_size_vs_oracle(B, N, g):
 
 
 @pytest.mark.parametrize("B,N,g", [(1, 1, 2), (3, 1, 4), (31, 7, 4), (33, 7, 8), (64, 7, 16), (5, 33, 4), (2, 59, 2),
-                                   (257, 5, 4), (1000, 3, 16), (4096, 7, 4), (4096, 30, 4), (2048, 59, 8), (9000, 2, 4), (20000, 7, 4)])
+                                   (257, 5, 4), (1000, 3, 16), (4096, 7, 4), (4096, 30, 4), (2048, 59, 8), (9000, 2, 4), (20000, 7, 4),
+                                   (37, 15, 4), (37, 16, 4), (40, 17, 2), (21, 18, 8)])
 def test_vae_fused_matches_layerwise(B, N, g):
     """The fused four-launch step against the one-launch-per-layer path on the
     same device and inputs: ragged batch sizes, one car per lane, lanes longer
@@ -273,3 +274,30 @@ def test_vae_encode_decode_fused_vs_oracle(g):
     # the per-layer path gives the same numbers
     el = _enc(g, init, fused=False)
     scaled_close("decode_batch per-layer", el.decode_batch(goal, loc, eps).cpu().numpy(), want.numpy(), atol_rel=5e-6)
+
+
+def test_vae_train_step_rejects_misaligned_layout():
+    """The fused step reads weight rows 16 bytes at a time: a layout whose weight offsets are not
+    multiples of four floats is refused before any launch, with a message."""
+    import ctypes
+    from hhrl_vae_amd import _lib as L
+    lib = L.load()
+    from hhrl_vae_amd.algorithm import Encoder
+    enc = Encoder(2, 4, device="cuda:0", seed=3)
+    B, N, g = 8, 3, 4
+    x = torch.rand(B, N, 2, device="cuda:0")
+    eps = torch.randn(B, g, device="cuda:0")
+    n_flat = enc.layout.size
+    ws = torch.zeros(lib.hhrl_vae_workspace_floats(B, N, g, n_flat), device="cuda:0")
+    loss = torch.zeros(1, device="cuda:0")
+    off = list(enc._offsets)
+    bad = (ctypes.c_long * len(off))(*off)
+    bad[18] += 2                                   # func.0 weight
+    rc = lib.hhrl_vae_train_step(enc.params.base_ptr, enc.opt.g.base_ptr, bad, n_flat, x.data_ptr(), eps.data_ptr(),
+                                 B, N, g, 1.0 / (B * N), loss.data_ptr(), ws.data_ptr(), None)
+    assert rc != 0 and b"aligned" in lib.hhrl_last_error()
+    good = (ctypes.c_long * len(off))(*off)
+    rc = lib.hhrl_vae_train_step(enc.params.base_ptr, enc.opt.g.base_ptr, good, n_flat, x.data_ptr(), eps.data_ptr(),
+                                 B, N, g, 1.0 / (B * N), loss.data_ptr(), ws.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert rc == 0 and np.isfinite(float(loss[0]))

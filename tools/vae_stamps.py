@@ -23,7 +23,7 @@ from hhrl_vae_amd.algorithm import Encoder
 
 CAR = ["start", "weights in LDS", "tile inputs", "func.0 fwd (element-wise)", "func.2 fwd", "func.4+err", "func.4 bwd",
        "func.2 bwd products", "mask, column sums, df1 image", "per-lane sums of df1", "pre-combine barrier",
-       "quarters in LDS", "slab written"]
+       "per-wave buffers in LDS", "slab written"]
 CHAIN = ["start", "weights in LDS", "cars staged", "phi.0", "phi.2", "rho.0", "rho.2", "heads", "reparam", "dec.0", "dec.2"]
 LFWD = CHAIN + ["U = d2 A^T + q", "activations stored"]
 LBWD = ["start", "weights, activations, S in LDS", "func.0 lane part (dd2, dA)", "dec.2 bwd", "dec.0 bwd", "latent", "heads bwd", "rho.2 bwd",
