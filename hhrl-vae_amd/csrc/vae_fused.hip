@@ -1198,6 +1198,12 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
   f32x16 aRho0 = splat(0.f), aPhi2 = splat(0.f), aF0 = splat(0.f);
   // bias gradients: one thread owns a column of a layer
   float bDec2 = 0.f, bDec0 = 0.f, bHead = 0.f, bRho2 = 0.f, bRho0 = 0.f, bPhi2 = 0.f;
+  // With helper waves the column sums belong to their threads (index bt), so that no matrix wave carries
+  // them on top of its products; without, to the threads that had them before.
+  const int bt = NT == 512 ? tid - 256 : tid;
+  const int bt_dec0 = NT == 512 ? bt : tid - 128;
+  const int bt_phi2 = NT == 512 ? bt : (wave == 1 ? lane : -1);
+  auto owns = [](int i, int n) { return i >= 0 && i < n; };
   float gPhi0a = 0.f, gPhi0b = 0.f, gPhi0c = 0.f;     // threads 0..47: dW_phi0[k][0], dW_phi0[k][1], db_phi0[k]
   float klacc = 0.f;
 
@@ -1212,15 +1218,15 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
   };
 
   auto write_f0 = [&]() {     // columns 0..31 of func.0's rows 32 wave .. 32 wave + 31
-    put_tile(g.off.w[FUNC0] + (long)32 * wave * 64, 64, 32, 0, 32, aF0);
+    if (mat) put_tile(g.off.w[FUNC0] + (long)32 * wave * 64, 64, 32, 0, 32, aF0);
   };
   auto write_dec2 = [&]() {
-    put_tile(g.off.w[DEC2], 128, 32, 32 * wave, 128, aDec2);
-    if (tid < 32) slab[g.off.b[DEC2] + tid] = bDec2;
+    if (mat) put_tile(g.off.w[DEC2], 128, 32, 32 * wave, 128, aDec2);
+    if (owns(bt, 32)) slab[g.off.b[DEC2] + bt] = bDec2;
   };
   auto write_dec0 = [&]() {
-    put_tile(g.off.w[DEC0] + (long)32 * wave * gd, gd, 32, 0, gd, aDec0);
-    if (tid >= 128) slab[g.off.b[DEC0] + tid - 128] = bDec0;
+    if (mat) put_tile(g.off.w[DEC0] + (long)32 * wave * gd, gd, 32, 0, gd, aDec0);
+    if (owns(bt_dec0, 128)) slab[g.off.b[DEC0] + bt_dec0] = bDec0;
   };
   auto write_heads = [&]() {
     if (wave < 2) {
@@ -1240,22 +1246,24 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
         }
       }
     }
-    if (tid < gd) slab[g.off.b[MEAN] + tid] = bHead;
-    else if (tid < 2 * gd) slab[g.off.b[LOGVAR] + tid - gd] = bHead;
+    if (owns(bt, gd)) slab[g.off.b[MEAN] + bt] = bHead;
+    else if (owns(bt, 2 * gd)) slab[g.off.b[LOGVAR] + bt - gd] = bHead;
   };
   auto write_rho2 = [&]() {
-    const int it = wave >> 1, jt0 = (wave & 1) * 2;
-    put_tile(g.off.w[RHO2] + (long)32 * it * 128, 128, 32, 32 * jt0, 128, aRho2a);
-    put_tile(g.off.w[RHO2] + (long)32 * it * 128, 128, 32, 32 * (jt0 + 1), 128, aRho2b);
-    if (tid < 64) slab[g.off.b[RHO2] + tid] = bRho2;
+    if (mat) {
+      const int it = wave >> 1, jt0 = (wave & 1) * 2;
+      put_tile(g.off.w[RHO2] + (long)32 * it * 128, 128, 32, 32 * jt0, 128, aRho2a);
+      put_tile(g.off.w[RHO2] + (long)32 * it * 128, 128, 32, 32 * (jt0 + 1), 128, aRho2b);
+    }
+    if (owns(bt, 64)) slab[g.off.b[RHO2] + bt] = bRho2;
   };
   auto write_rho0 = [&]() {
-    put_tile(g.off.w[RHO0] + (long)32 * wave * 32, 32, 32, 0, 32, aRho0);
-    if (tid < 128) slab[g.off.b[RHO0] + tid] = bRho0;
+    if (mat) put_tile(g.off.w[RHO0] + (long)32 * wave * 32, 32, 32, 0, 32, aRho0);
+    if (owns(bt, 128)) slab[g.off.b[RHO0] + bt] = bRho0;
   };
   auto write_phi2 = [&]() {
     if (wave == 0) put_tile(g.off.w[PHI2], 16, 32, 0, 16, aPhi2);
-    if (wave == 1 && lane < 32) slab[g.off.b[PHI2] + lane] = bPhi2;
+    if (owns(bt_phi2, 32)) slab[g.off.b[PHI2] + bt_phi2] = bPhi2;
   };
 
   int tile = blockIdx.x;
@@ -1355,7 +1363,7 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
       wave_mma<1, 32, 1, 129, 33, 1>(acc, Ir1 + 32 * wave, Itmp, lane);
       aF0 = acc[0];
     }
-    if (SINGLE && mat) write_f0();
+    if (SINGLE) write_f0();
     __syncthreads();
     HHRL_STAMP(2, 2);
     actR.commit(lds, tid);               // r1 over S, r2: first read after the next barriers
@@ -1364,7 +1372,6 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
       f32x16 acc[1] = {aDec2};
       wave_mma<1, 32, 1, 33, 129, 1>(acc, Id2, Id1 + 32 * wave, lane);
       aDec2 = acc[0];
-      if (tid < 32) bDec2 += colsum32(Id2, 33, tid);
       f32x16 d[1];
       d[0] = splat(0.f);
       wave_mma<1, 32, 33, 1, 129, 1>(d, Id2, lds + LW_DEC2 + 32 * wave, lane);
@@ -1375,7 +1382,8 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
         *p = *p > 0.f ? d[0][i] : 0.f;
       }
     }
-    if (SINGLE && mat) write_dec2();
+    if (owns(bt, 32)) bDec2 += colsum32(Id2, 33, bt);
+    if (SINGLE) write_dec2();
     __syncthreads();
     HHRL_STAMP(2, 3);
     // ---- decoder.0 backward: dW[128][g] += dd1^T z (row tile `wave`), db, dz = dd1 W (waves 0 and 1, 16 rows each)
@@ -1383,14 +1391,13 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
       f32x16 acc[1] = {aDec0};
       wave_mma<1, 32, 1, 129, 17, 1>(acc, Id1 + 32 * wave, Iz, lane);
       aDec0 = acc[0];
-      if (wave >= 2) {
-        bDec0 += colsum32(Id1, 129, tid - 128);
-      } else {
+      if (wave < 2) {
         const f32x4 c = wave_mma16<128, 129, 1, 17, 1>(Id1 + 16 * wave * 129, lds + LW_DEC0, lane, 0.f);
         store_block16<33>(Itmp, 16 * wave, 0, c, lane);
       }
     }
-    if (SINGLE && mat) write_dec0();
+    if (owns(bt_dec0, 128)) bDec0 += colsum32(Id1, 129, bt_dec0);
+    if (SINGLE) write_dec0();
     __syncthreads();
     HHRL_STAMP(2, 4);
     // ---- latent gradient (KL + reparameterisation): dml = [dz + mean | dz*eps*0.5*std + 0.5*(exp(lv)-1) | 0...]
@@ -1424,11 +1431,11 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
       } else if (mat) {
         wave_mma<1, 32, 33, 1, 65, 1>(d, Idml, lds + LW_HEAD + 32 * (wave - 2), lane);
       }
-      if (tid < 32) bHead += colsum32(Idml, 33, tid);
+      if (owns(bt, 32)) bHead += colsum32(Idml, 33, bt);
       __syncthreads();
       if (wave >= 2 && mat) store_tile<65>(Ir2, 32 * (wave - 2), d[0], lane);
     }
-    if (SINGLE && mat) write_heads();
+    if (SINGLE) write_heads();
     __syncthreads();
     HHRL_STAMP(2, 6);
     // ---- rho.2 backward: dW[64][128] += dr2^T r1 (two tiles per wave), db, dr1 = (dr2 W) o relu'(r1) in place
@@ -1441,9 +1448,9 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
         wave_mma<2, 32, 1, 65, 129, 1>(acc, Ir2 + 32 * it, Ir1 + 32 * jt0, lane);
         aRho2a = acc[0];
         aRho2b = acc[1];
-        if (tid < 64) bRho2 += colsum32(Ir2, 65, tid);
         wave_mma<1, 64, 65, 1, 129, 1>(d, Ir2, lds + LW_RHO2 + 32 * wave, lane);
       }
+      if (owns(bt, 64)) bRho2 += colsum32(Ir2, 65, bt);
       __syncthreads();                                  // every wave is done reading r1
       if (mat) {
 #pragma unroll
@@ -1453,7 +1460,7 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
         }
       }
     }
-    if (SINGLE && mat) write_rho2();
+    if (SINGLE) write_rho2();
     __syncthreads();
     HHRL_STAMP(2, 7);
     // ---- rho.0 backward: dW[128][32] += dr1^T pooled (row tile `wave`), db, dpooled = dr1 W (16x16 blocks) -> ml slot
@@ -1461,11 +1468,11 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
       f32x16 acc[1] = {aRho0};
       wave_mma<1, 32, 1, 129, 33, 1>(acc, Ir1 + 32 * wave, Ipool, lane);
       aRho0 = acc[0];
-      if (tid < 128) bRho0 += colsum32(Ir1, 129, tid);
       const f32x4 c = wave_mma16<128, 129, 1, 33, 1>(Ir1 + 16 * rb * 129, lds + LW_RHO0 + 16 * cb, lane, 0.f);
       store_block16<33>(Iml, 16 * rb, 16 * cb, c, lane);
     }
-    if (SINGLE && mat) write_rho0();
+    if (owns(bt, 128)) bRho0 += colsum32(Ir1, 129, bt);
+    if (SINGLE) write_rho0();
     __syncthreads();
     HHRL_STAMP(2, 8);
     // ---- phi.2 backward on the summed hidden: dW[32][16] += dpooled^T h1s (wave 0), db = N colsum(dpooled) (wave 1),
@@ -1474,13 +1481,12 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
       f32x16 acc[1] = {aPhi2};
       wave_mma<1, 32, 1, 33, 33, 1>(acc, Iml, Ih1, lane);       // columns >= 16 are junk, dropped below
       aPhi2 = acc[0];
-    } else if (wave == 1) {
-      if (lane < 32) bPhi2 += (float)g.N * colsum32(Iml, 33, lane);
-    } else if (mat) {
+    } else if (wave == 2 || wave == 3) {
       const f32x4 c = wave_mma16<32, 33, 1, 17, 1>(Iml + 16 * (wave - 2) * 33, lds + LW_PHI2, lane, 0.f);
       store_block16<33>(Itmp, 16 * (wave - 2), 0, c, lane);
     }
-    if (SINGLE && mat) write_phi2();
+    if (owns(bt_phi2, 32)) bPhi2 += (float)g.N * colsum32(Iml, 33, bt_phi2);
+    if (SINGLE) write_phi2();
     __syncthreads();
     HHRL_STAMP(2, 9);
     // ---- phi.0 backward: per (lane, hidden unit) walk the cars again and apply the ReLU mask
