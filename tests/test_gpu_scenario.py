@@ -1,0 +1,154 @@
+"""Four-intersection scenario (tools/four_intersections.py) on the GPU classes against the same stream
+driven through the CPU oracle: the reference's per-second call cadence (train.py:183-204, agent.py:309-494,
+736-867) with full-size networks — Encoder(2, 2), HATD3Triple (13/13/25 x T=10, actions 1/4/4), WorkerTD3
+(11 + goal 6) — replay filling, exploration, `learn` calls of both levels interleaved with `encode`,
+`decode` and `choose_*`.  Every value that flows between calls is compared, and the parameters at the end.
+Bar: fp32, rtol 1e-4 with the absolute floors of the other tests (parameters: + 5e-3 * lr * steps, Adam's
+first steps move a weight by ~lr whatever the size of its gradient)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import hhrl_oracle as O
+from golden_util import assert_close
+from test_gpu_kernels import scaled_close
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+import four_intersections as S  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+class OracleNet:
+    """The reference's replay and call surface (algorithm.py:252, 273-281, 709, 750-766, 1276, 1299-1314)
+    around the oracle's functional TD3."""
+
+    def __init__(self, kind, cfg, states):
+        self.fam = O.family_from_cfg(kind, cfg)
+        names = self.fam.actor_names()
+        self.td3 = O.TD3(self.fam, [states[n] for n in names], states["critic"])
+        self.batch_size = self.fam.batch_size
+        self.memory_capacity = cfg["memory_capacity"]
+        self.learn_begin = self.memory_capacity * cfg["learn_start_ratio"]
+        self.memory = np.zeros((self.memory_capacity, self.fam.row_width))
+        self.pointer = 0
+
+    def store_transition(self, *parts):
+        self.memory[self.pointer % self.memory_capacity, :] = np.hstack(parts)
+        self.pointer += 1
+
+    def choose_time_action(self, o):
+        return self.td3.choose(0, o)
+
+    def choose_phase_action(self, o):
+        return self.td3.choose(1, o)
+
+    def choose_goal(self, o):
+        return self.td3.choose(2, o)
+
+    def choose_action(self, o, g):
+        return self.td3.choose(0, o, g)
+
+    def policy(self, o, g):
+        return self.td3.policy(o, g)
+
+    def learn(self, worker_policy=None, indices=None, noise=None, order=None):
+        b = O.split_rows(self.fam, self.memory[indices, :])
+        self.td3.learn(b, [torch.as_tensor(n) for n in noise], order)
+
+
+class OracleEncoder:
+    def __init__(self, state, g):
+        self.goal_dim = g
+        self.vae = O.VAE(state, g)
+
+    def encode(self, x):
+        return self.vae.encode(x)
+
+    def decode(self, goal, loc, eps=None):
+        return self.vae.decode(np.asarray(goal).reshape(1, -1), np.asarray(loc).reshape(1, 1),
+                               torch.as_tensor(eps).reshape(1, -1))[0]
+
+
+def _cpu(sd):
+    return {k: v.detach().cpu().clone() for k, v in sd.items()}
+
+
+def test_four_intersections_stream_matches_oracle():
+    import hhrl_vae_amd.algorithm as A
+    seconds = 60
+    mcfg, wcfg = S.make_cfgs(manager_capacity=320, worker_capacity=160)      # learn_begin: 16 and 64 rows
+    enc, mgr, wrk = A.Encoder(2, 2, seed=11), A.HATD3Triple(mcfg, seed=12), A.WorkerTD3(wcfg, seed=13)
+    o_enc = OracleEncoder(_cpu(enc.state_dict()), 2)
+    o_mgr = OracleNet("triple", mcfg, {n: _cpu(sd) for n, sd in mgr.state_dicts().items()})
+    o_wrk = OracleNet("worker", wcfg, {n: _cpu(sd) for n, sd in wrk.state_dicts().items()})
+    got, want = {}, {}
+    c_got = S.run(enc, mgr, wrk, S.Stream(green=6), seconds, seed=5, trace=got)
+    c_want = S.run(o_enc, o_mgr, o_wrk, S.Stream(green=6), seconds, seed=5, trace=want)
+    for k in c_want:
+        if not k.startswith("wall_"):
+            assert c_got[k] == c_want[k], (k, c_got[k], c_want[k])
+    # the cadence itself: 2 x 32 encodes per second, both levels learned, policies consulted
+    assert c_got["encode"] == 2 * 32 * seconds
+    assert c_got["learn_worker"] >= 40 and c_got["learn_manager"] >= 8
+    assert c_got["choose_worker"] > 0 and c_got["choose_manager"] > 0 and c_got["decode"] > 0
+    assert c_got["store_manager"] == mgr.pointer == o_mgr.pointer and c_got["store_worker"] == wrk.pointer == o_wrk.pointer
+    for key in ("enc", "adv", "a_worker", "a_time", "a_phase", "a_goal"):
+        assert len(got[key]) == len(want[key]) > 0, key
+        g, w = np.stack(got[key]).astype(np.float64), np.stack(want[key]).astype(np.float64)
+        # actions follow parameters that have taken Adam steps: their own floor is the parameters'
+        scaled_close(key, g, w, rtol=1e-4, atol_rel=2e-6 if key in ("enc", "adv") else 2e-4)
+    n = min(mgr.pointer, 320)
+    scaled_close("manager replay", mgr.memory[:n], o_mgr.memory[:n], atol_rel=2e-4)
+    n = min(wrk.pointer, 160)
+    scaled_close("worker replay", wrk.memory[:n], o_wrk.memory[:n], atol_rel=2e-4)
+
+    def params_close(name, got_sd, want_p, lr, steps):
+        for k, w in want_p.items():
+            w = w.detach().numpy()
+            assert_close("%s/%s" % (name, k), got_sd[k].cpu().numpy(), w, rtol=1e-4,
+                         atol=2e-6 * max(float(np.max(np.abs(w))), 1e-30) + 5e-3 * lr * steps)
+
+    for net, onet, tag in ((mgr, o_mgr, "manager"), (wrk, o_wrk, "worker")):
+        steps = onet.td3.total_it
+        assert net.total_it == steps > 0
+        sds, tgt = net.state_dicts(), net.target_state_dicts()
+        params_close(tag + "/critic", sds["critic"], onet.td3.critic, 1e-3, steps)
+        params_close(tag + "/critic_target", tgt["critic"], onet.td3.critic_target, 1e-3, steps)
+        for k, nme in enumerate(net.actor_names):
+            params_close(tag + "/" + nme, sds[nme], onet.td3.actors[k], 1e-4, steps)
+            params_close(tag + "/" + nme + "_target", tgt[nme], onet.td3.actor_targets[k], 1e-4, steps)
+
+
+def test_four_intersections_batched_inference_same_values():
+    """The batched inference calls (eight lanes per `encode_lanes`, both advised speeds per `decode_batch`)
+    feed the stream the same values as one call per lane / location, to fp32 rounding (the ragged-lane
+    kernel sums a lane's cars in another order than the fixed-count one): same call counts, encodings and
+    advised speeds within 2e-6 of the tensor's scale, actions, replay rows and parameters within the
+    bars of the oracle comparison above."""
+    import hhrl_vae_amd.algorithm as A
+    mcfg, wcfg = S.make_cfgs(manager_capacity=320, worker_capacity=160)
+    outs = []
+    for batched in (False, True):
+        enc, mgr, wrk = A.Encoder(2, 2, seed=11), A.HATD3Triple(mcfg, seed=12), A.WorkerTD3(wcfg, seed=13)
+        tr = {}
+        c = S.run(enc, mgr, wrk, S.Stream(green=6), 40, seed=7, trace=tr, batched=batched)
+        torch.cuda.synchronize()
+        outs.append((c, tr, mgr.memory.copy(), wrk.memory.copy(), mgr.state_dicts(), wrk.state_dicts(), wrk.total_it))
+    (c0, t0, mm0, wm0, ms0, ws0, steps), (c1, t1, mm1, wm1, ms1, ws1, _) = outs
+    assert c1["encode"] * 16 == c0["encode"] and c1["decode"] * 2 == c0["decode"]
+    assert c0["learn_worker"] == c1["learn_worker"] > 0 and c0["learn_manager"] == c1["learn_manager"] > 0
+    for key in t0:
+        scaled_close(key, np.stack(t1[key]), np.stack(t0[key]), atol_rel=2e-6 if key in ("enc", "adv") else 2e-4)
+    scaled_close("manager replay", mm1, mm0, atol_rel=2e-4)
+    scaled_close("worker replay", wm1, wm0, atol_rel=2e-4)
+    for a, b in ((ms0, ms1), (ws0, ws1)):
+        for n in a:
+            lr = 1e-3 if n == "critic" else 1e-4
+            for k in a[n]:
+                w = a[n][k].cpu().numpy()
+                assert_close("%s/%s" % (n, k), b[n][k].cpu().numpy(), w, rtol=1e-4,
+                             atol=2e-6 * max(float(np.max(np.abs(w))), 1e-30) + 5e-3 * lr * steps)
