@@ -72,6 +72,39 @@ class _Work:
         self.d_h2, self.d_h1 = e(M, 32), e(M, 16)
 
 
+class _InferIO:
+    """One pinned host block and one device block each way for the inference calls: a call writes all of
+    its inputs into the host block, uploads them with ONE transfer, launches, downloads the result with
+    ONE transfer and waits for the stream.  Blocks grow by doubling; a call owns them until it returns
+    (the class surface is used from one thread, like the reference's)."""
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.n_in = self.n_out = 0
+        self.h_in = self.d_in = self.h_out = self.d_out = None
+
+    def reserve(self, n_in: int, n_out: int) -> None:
+        if n_in > self.n_in:
+            self.n_in = max(1024, 2 * self.n_in, n_in)
+            self.h_in = torch.zeros(self.n_in, dtype=torch.float32).pin_memory()
+            self.d_in = ops.dev_empty(self.n_in, device=self.dev)
+            self.h_in_np = self.h_in.numpy()
+            self.h_in_i32 = self.h_in_np.view(np.int32)
+        if n_out > self.n_out:
+            self.n_out = max(1024, 2 * self.n_out, n_out)
+            self.h_out = torch.zeros(self.n_out, dtype=torch.float32).pin_memory()
+            self.d_out = ops.dev_empty(self.n_out, device=self.dev)
+            self.h_out_np = self.h_out.numpy()
+
+    def upload(self, n: int) -> None:
+        self.d_in[:n].copy_(self.h_in[:n], non_blocking=True)
+
+    def download(self, n: int) -> np.ndarray:
+        self.h_out[:n].copy_(self.d_out[:n], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return self.h_out_np[:n].copy()
+
+
 class Encoder:
     """Drop-in for the reference's `Encoder(car_info_dim, goal_dim)`.
 
@@ -132,6 +165,8 @@ class Encoder:
         if group is not None:
             import torch.distributed as dist
             self.world_size = dist.get_world_size(group)
+        self._io = _InferIO(self.device)
+        self._host_rng = np.random.default_rng(3407 if seed is None else seed)      # decode()'s noise (algorithm.py:125)
 
     # ------------------------------------------------------------ helpers
     def _ws(self, B: int, N: int) -> _Work:
@@ -313,10 +348,32 @@ class Encoder:
         """Encoder.encode (algorithm.py:109-116): one lane [N, 2] -> mean||logvar [2g]."""
         if len(x) == 0:
             return np.zeros((self.goal_dim * 2))
+        if self.fused and not isinstance(x, torch.Tensor):
+            xs = np.asarray(x, dtype=np.float32)
+            if xs.ndim != 2 or xs.shape[1] != 2:
+                raise ValueError("encode expects one lane [N, 2]")
+            return self._encode_host(xs, None, 1, int(xs.shape[0]))[0]
         xt = self._to_device(x)
         if xt.dim() != 2 or xt.shape[1] != 2:
             raise ValueError("encode expects one lane [N, 2]")
         return self._encode_dev(xt, None, 1, int(xt.shape[0]))[0].cpu().numpy()
+
+    def _encode_host(self, cars: np.ndarray, start: Optional[np.ndarray], B: int, N: int) -> np.ndarray:
+        """Fused encoder on host data: cars [n, 2] (and the lanes' start rows, int32 [B + 1]) go up in one
+        pinned block, mean||logvar [B, 2g] comes back in one."""
+        io, g2 = self._io, 2 * self.goal_dim
+        n_car = cars.size
+        n_car_al = (n_car + 3) & ~3                          # lane_start begins on a 16-byte boundary
+        n_in = n_car_al + (B + 1 if start is not None else 0)
+        io.reserve(n_in, B * g2)
+        io.h_in_np[:n_car] = cars.reshape(-1)
+        if start is not None:
+            io.h_in_i32[n_car_al:n_in] = start
+        io.upload(n_in)
+        check(self._lib.hhrl_vae_encode(self.params.base_ptr, self._offsets, self.layout.size, P(io.d_in),
+                                        P(io.d_in, n_car_al) if start is not None else None, B, N,
+                                        self.goal_dim, P(io.d_out), g2, _lib.stream_ptr()))
+        return io.download(B * g2).reshape(B, g2)
 
     def encode_batch(self, lanes: torch.Tensor) -> torch.Tensor:
         """[B, N, 2] lanes with a common car count -> [B, 2g] on the device."""
@@ -335,8 +392,7 @@ class Encoder:
         cars = np.concatenate([np.asarray(l, dtype=np.float32).reshape(-1, 2) for l in lanes if len(l)], axis=0)
         start = np.zeros(B + 1, dtype=np.int32)
         np.cumsum(counts, out=start[1:])
-        out = self._encode_dev(torch.from_numpy(cars).to(self.device), torch.from_numpy(start).to(self.device), B, 0)
-        return out.cpu().numpy()
+        return self._encode_host(cars, start, B, 0)
 
     def decode_batch(self, goal, loc, eps=None) -> torch.Tensor:
         """goal [B, 2g] (mean||logvar), loc [B, N] -> decoded speeds [B, N] on the device.  eps [B, g]:
@@ -373,7 +429,36 @@ class Encoder:
         goal_np = np.asarray(goal, dtype=np.float32).reshape(1, 2 * g)
         loc_np = np.asarray(loc, dtype=np.float32).reshape(1, 1)
         eps_np = None if eps is None else np.asarray(eps, dtype=np.float32).reshape(1, g)
+        if self.fused:
+            return self.decode_host(goal_np, loc_np, eps_np)[0]
         return self.decode_batch(goal_np, loc_np, eps_np)[0].cpu().numpy()
+
+    def decode_host(self, goal, loc, eps=None) -> np.ndarray:
+        """decode_batch for host data with the result on the host: goal [B, 2g], loc [B, N] and the noise
+        [B, g] (drawn with the host generator seeded at construction when omitted) go up in one pinned block,
+        the speeds [B, N] come back in one."""
+        if not self.fused:
+            return self.decode_batch(goal, loc, eps).cpu().numpy()
+        g = self.goal_dim
+        goal_np = np.asarray(goal, dtype=np.float32).reshape(-1, 2 * g)
+        B = goal_np.shape[0]
+        loc_np = np.asarray(loc, dtype=np.float32).reshape(B, -1)
+        N = loc_np.shape[1]
+        if eps is None:
+            eps_np = self._host_rng.standard_normal((B, g), dtype=np.float32)
+        else:
+            eps_np = np.asarray(eps, dtype=np.float32).reshape(B, g)
+        io = self._io
+        o_eps, o_loc = B * 2 * g, B * 3 * g
+        n_in = o_loc + B * N
+        io.reserve(n_in, B * N)
+        io.h_in_np[:o_eps] = goal_np.reshape(-1)
+        io.h_in_np[o_eps:o_loc] = eps_np.reshape(-1)
+        io.h_in_np[o_loc:n_in] = loc_np.reshape(-1)
+        io.upload(n_in)
+        check(self._lib.hhrl_vae_decode(self.params.base_ptr, self._offsets, self.layout.size, P(io.d_in), 2 * g,
+                                        P(io.d_in, o_eps), P(io.d_in, o_loc), N, B, N, g, P(io.d_out), N, _lib.stream_ptr()))
+        return io.download(B * N).reshape(B, N)
 
     # ------------------------------------------------------------ checkpoints
     def state_dict(self) -> Dict[str, torch.Tensor]:

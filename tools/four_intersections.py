@@ -102,7 +102,7 @@ def run(encoder, manager, worker, stream: Stream, seconds: int, seed: int = 0, v
     calls (encodings, advised speeds, actions) for comparison between implementations.  `batched` uses
     the calls the reference does not have: the eight lanes of a light in one `encode_lanes` call (shared
     by manager and worker, which encode the same lanes) and the two advised speeds of a CAV in one
-    `decode_batch` call; the values are the same."""
+    `decode_host` call; the values are the same."""
     rng = np.random.RandomState(seed)
     g2 = 2 * encoder.goal_dim
     T = manager.fam.streams[0].T
@@ -205,8 +205,7 @@ def run(encoder, manager, worker, stream: Stream, seconds: int, seed: int = 0, v
                 eps = rng.standard_normal((2, encoder.goal_dim)).astype(np.float32)
                 nxt = (ov[0] * LANE_LENGTH + ov[1] * MAX_SPEED) / LANE_LENGTH
                 if batched:
-                    both = timed("decode", lambda: encoder.decode_batch(np.stack([goal_state[L][l]] * 2), [[ov[0]], [nxt]],
-                                                                        eps).cpu().numpy())
+                    both = timed("decode", encoder.decode_host, np.stack([goal_state[L][l]] * 2), [[ov[0]], [nxt]], eps)
                     adv0, adv1 = both[0].tolist(), both[1].tolist()
                     cnt["decode"] += 1
                 else:
