@@ -7,6 +7,9 @@ kept under profiles/:
     <tag>_hbm_traffic.json          HBM bytes per launch of the fused VAE kernels from the PMC passes:
                                     reads = 2 x FETCH_SIZE (gfx950 tallies 128-B requests at 64 B),
                                     writes = WRITE_SIZE, both reported by rocprofv3 in KiB
+    <tag>_mfma_util.json            matrix-core counters per launch of the same kernels (fourth pass, if present):
+                                    SQ_VALU_MFMA_BUSY_CYCLES (cycles a SIMD's matrix pipe is busy, summed over SIMDs),
+                                    SQ_INSTS_VALU_MFMA_MOPS_F32 (executed matrix FLOPs / 512), GRBM_GUI_ACTIVE
 
 usage: python tools/summarize_prof.py <tag>        (on the CPU box, after the GPU call has merged its files)
 """
@@ -69,6 +72,48 @@ def main():
         f.write("\n")
     for k, v in doc["kernels"].items():
         print("%-28s %10.0f B/launch" % (k, v["hbm_bytes_per_launch"]))
+    mfma = glob.glob(src + "/mfma/**/*_counter_collection.csv", recursive=True)
+    if len(mfma) == 1:
+        mfma_summary(mfma[0], os.path.join(dst, tag + "_kernel_stats.csv"), os.path.join(dst, tag + "_mfma_util.json"), tag, workload)
+
+
+N_SIMD = 1024           # 256 CUs x 4
+CLOCK_GHZ = 2.4         # MI355X peak engine clock: the clock the 157.3 TFLOP/s fp32 matrix peak is quoted at
+
+
+def mfma_summary(path, stats_csv, out_path, tag, workload):
+    avg_us = {}
+    with open(stats_csv, newline="") as f:
+        for row in csv.DictReader(f):
+            for k in KERNELS:
+                if k in row["Name"]:
+                    avg_us[k] = float(row["AverageNs"]) / 1e3
+    names = ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_BUSY_CYCLES", "SQ_WAVES", "GRBM_GUI_ACTIVE")
+    c = {n: counter_per_launch(path, n) for n in names}
+    doc = {"workload": workload,
+           "command": "tools/profile_bench.sh %s, pass 4 (rocprofv3 --pmc %s)" % (tag, " ".join(names)),
+           "definitions": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles); kernel cycles = "
+                          "the kernel-trace pass's average duration x 2.4 GHz (mfma_busy_frac) or GRBM_GUI_ACTIVE / 8 XCDs "
+                          "(mfma_busy_frac_gui_active; reads high on dispatches this short); executed_matrix_flops = 512 x "
+                          "SQ_INSTS_VALU_MFMA_MOPS_F32; executed_tflops = that / average duration",
+           "kernels": {}}
+    for k in KERNELS:
+        if k not in c["SQ_VALU_MFMA_BUSY_CYCLES"] or k not in avg_us:
+            continue
+        busy, mops = c["SQ_VALU_MFMA_BUSY_CYCLES"][k], c["SQ_INSTS_VALU_MFMA_MOPS_F32"][k]
+        gui = c["GRBM_GUI_ACTIVE"].get(k, 0.0)
+        cyc = avg_us[k] * 1e-6 * CLOCK_GHZ * 1e9
+        doc["kernels"][k] = {"avg_launch_us": avg_us[k], "SQ_VALU_MFMA_BUSY_CYCLES": busy, "SQ_INSTS_VALU_MFMA_MOPS_F32": mops,
+                             "SQ_BUSY_CYCLES": c["SQ_BUSY_CYCLES"].get(k), "SQ_WAVES": c["SQ_WAVES"].get(k), "GRBM_GUI_ACTIVE": gui,
+                             "mfma_busy_frac": busy / (N_SIMD * cyc),
+                             "mfma_busy_frac_gui_active": busy / (N_SIMD * gui / 8.0) if gui else None,
+                             "executed_matrix_flops": 512.0 * mops,
+                             "executed_tflops": 512.0 * mops / (avg_us[k] * 1e-6) / 1e12}
+    with open(out_path, "w") as f:
+        json.dump(doc, f, indent=1)
+        f.write("\n")
+    for k, v in doc["kernels"].items():
+        print("%-28s mfma busy %.3f  executed %.1f TFLOP/s" % (k, v["mfma_busy_frac"], v["executed_tflops"]))
 
 
 if __name__ == "__main__":
