@@ -163,17 +163,19 @@ def inference_latency(enc, device) -> dict:
     return out
 
 
-def pmc_traffic(workload: str, kernel: str):
+def pmc_traffic(workload: str, kernel: str, suffix: str = "_hbm_traffic.json", field: str = "hbm_bytes_per_launch"):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary
     of this workload (rocprofv3 FETCH_SIZE / WRITE_SIZE passes, read bytes
-    doubled as gfx950 requires); None when no summary covers the workload."""
+    doubled as gfx950 requires); None when no summary covers the workload.
+    With suffix "_mfma_util.json" / field "mfma_busy_frac": the matrix pipe's busy
+    share of the launch from the SQ_VALU_MFMA_BUSY_CYCLES pass."""
     import glob
     import re
 
     def order(path):                       # r01_v8 before r01_v11: numbers compare as numbers
         return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(path))]
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), key=order):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)), key=order):
         try:
             with open(path) as f:
                 d = json.load(f)
@@ -181,7 +183,7 @@ def pmc_traffic(workload: str, kernel: str):
             continue
         k = d.get("kernels", {}).get(kernel)
         if d.get("workload") == workload and k is not None:
-            best = {"bytes": k["hbm_bytes_per_launch"], "source": os.path.relpath(path, ROOT)}
+            best = {"bytes": k[field], "source": os.path.relpath(path, ROOT)}
     return best
 
 
@@ -289,6 +291,10 @@ def main() -> None:
             roof["traffic"] = tr["bytes"]
             roof["traffic_unit"] = "bytes per launch"
             roof["traffic_source"] = tr["source"]
+        mb = pmc_traffic(workload, dom_name, "_mfma_util.json", "mfma_busy_frac")
+        if mb is not None:
+            roof["mfma_busy"] = mb["bytes"]
+            roof["mfma_busy_source"] = mb["source"]
         # the same kernel priced by the matrix-core FLOPs it executes (see vae_executed_flops_per_lane)
         lane_macs = 512 + 4096 + 8192 + 128.0 * g + 128.0 * g + 4096
         executed = {"vae_car_fwd_bwd_kernel": 2.0 * (3 * 4096 + 16 * 128) * B * N,
