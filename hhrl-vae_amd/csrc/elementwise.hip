@@ -97,23 +97,45 @@ __global__ __launch_bounds__(256) void twin_mse_kernel(const float* __restrict__
 // One coalesced pass: reads p,g,m,v (16 B each), writes p,m,v: 28 B / parameter.
 // copy_dst (optional): one float copied from copy_src by the first thread, for a value that travels behind
 // the gradient (the all-reduced loss of a data-parallel step)
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ float4 ld4(const float4* a) {
+  if (NT) {
+    const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(a));
+    return make_float4(t.x, t.y, t.z, t.w);
+  }
+  return *a;
+}
+template <bool NT> __device__ __forceinline__ void st4(float4* a, const float4& x) {
+  if (NT) {
+    v4f t;
+    t.x = x.x; t.y = x.y; t.z = x.z; t.w = x.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(a));
+  } else {
+    *a = x;
+  }
+}
+
+// NT: non-temporal loads and stores, for buffers far larger than the caches (nothing of them is read again
+// before it is evicted): 5.3 against 4.6 TB/s at 10^8 parameters, where a plain copy with the same four-in,
+// three-out stream mix reaches 4.7-5.1 TB/s.  The networks of this package fit the caches and take NT = false.
+template <bool NT>
 __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* __restrict__ g, float* m, float* v, long n, AdamK k,
                                                    const float* copy_src, float* copy_dst) {
   if (copy_dst != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *copy_dst = *copy_src;
   const long n4 = n >> 2;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    float4 P = reinterpret_cast<float4*>(p)[i];
-    const float4 G = reinterpret_cast<const float4*>(g)[i];
-    float4 Mo = reinterpret_cast<float4*>(m)[i];
-    float4 V = reinterpret_cast<float4*>(v)[i];
+    float4 P = ld4<NT>(reinterpret_cast<const float4*>(p) + i);
+    const float4 G = ld4<NT>(reinterpret_cast<const float4*>(g) + i);
+    float4 Mo = ld4<NT>(reinterpret_cast<const float4*>(m) + i);
+    float4 V = ld4<NT>(reinterpret_cast<const float4*>(v) + i);
     adam_one(P.x, G.x, Mo.x, V.x, k);
     adam_one(P.y, G.y, Mo.y, V.y, k);
     adam_one(P.z, G.z, Mo.z, V.z, k);
     adam_one(P.w, G.w, Mo.w, V.w, k);
-    reinterpret_cast<float4*>(p)[i] = P;
-    reinterpret_cast<float4*>(m)[i] = Mo;
-    reinterpret_cast<float4*>(v)[i] = V;
+    st4<NT>(reinterpret_cast<float4*>(p) + i, P);
+    st4<NT>(reinterpret_cast<float4*>(m) + i, Mo);
+    st4<NT>(reinterpret_cast<float4*>(v) + i, V);
   }
   const long tail = n4 << 2;
   const long i = tail + (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -260,7 +282,10 @@ static int adam_launch(float* p, const float* g, float* m, float* v, long n, dou
   hipStream_t st = as_stream(stream);
   ProfScope ps("adam_kernel", st, 0.0, 28.0 * n);
   if (aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v)) {
-    hipLaunchKernelGGL(adam_kernel, dim3(stream_grid((n + 3) / 4)), dim3(256), 0, st, p, g, m, v, n, k, copy_src, copy_dst);
+    if (n >= (64L << 20))      // 4 x 256 MB and more: beyond the 256 MB Infinity Cache
+      hipLaunchKernelGGL(adam_kernel<true>, dim3(stream_grid((n + 3) / 4)), dim3(256), 0, st, p, g, m, v, n, k, copy_src, copy_dst);
+    else
+      hipLaunchKernelGGL(adam_kernel<false>, dim3(stream_grid((n + 3) / 4)), dim3(256), 0, st, p, g, m, v, n, k, copy_src, copy_dst);
   } else {
     hipLaunchKernelGGL(adam_scalar_kernel, dim3(stream_grid(n)), dim3(256), 0, st, p, g, m, v, n, k, copy_src, copy_dst);
   }

@@ -94,6 +94,30 @@ def test_argument_errors(env):
         L.check(lib.hhrl_fill(None, 4, 0.0, None))
 
 
+def test_adam_beyond_the_caches(env):
+    """Buffers of 64 Mi + 5 parameters take the non-temporal form of the Adam kernel (plus the scalar tail):
+    two steps against torch.optim.Adam on the CPU."""
+    lib, L, dev = env
+    n = (64 << 20) + 5
+    g = torch.Generator().manual_seed(7)
+    p = torch.randn(n, generator=g)
+    ref_p = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref_p], lr=1e-3)
+    pd = p.to(dev)
+    md, vd = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    for step in (1, 2):
+        gr = torch.randn(n, generator=g) * 0.1
+        ref_p.grad = gr.clone()
+        opt.step()
+        grd = gr.to(dev)
+        L.check(lib.hhrl_adam_step(pd.data_ptr(), grd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, 1e-3, 0.9, 0.999,
+                                   1e-8, step, 1.0, L.stream_ptr()))
+    scaled_close("p", pd.cpu().numpy(), ref_p.detach().numpy(), rtol=1e-5, atol_rel=1e-7)
+    st = opt.state[ref_p]
+    scaled_close("m", md.cpu().numpy(), st["exp_avg"].numpy(), rtol=1e-5)
+    scaled_close("v", vd.cpu().numpy(), st["exp_avg_sq"].numpy(), rtol=1e-5)
+
+
 @pytest.mark.parametrize("n", [1, 5, 64, 30912, 1216898 + 3])
 def test_adam_and_polyak(env, n):
     lib, L, dev = env
