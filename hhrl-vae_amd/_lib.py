@@ -98,6 +98,7 @@ SIGNATURES = {
     "hhrl_adam_step_copy": (_I, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _I, _D, _P, _P, _P]),
     "hhrl_adam_stage": (_I, [_P, _D, _D, _D, _D, _I, _D, _P]),
     "hhrl_adam_step_dev": (_I, [_P, _P, _P, _P, _L, _P, _P]),
+    "hhrl_adam_polyak_step_dev": (_I, [_P, _P, _P, _P, _L, _P, _P, _D, _P]),
     "hhrl_polyak_update": (_I, [_P, _P, _L, _D, _P]),
     "hhrl_prof_enable": (_I, [_I]),
     "hhrl_prof_reset": (_I, []),

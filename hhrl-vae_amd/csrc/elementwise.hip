@@ -160,13 +160,49 @@ __global__ void adam_stage_kernel(float* hyper, AdamK k) {
   }
 }
 
+__device__ __forceinline__ float polyak_one(float t, float p, float tau, float om) { return tau * p + om * t; }
+
+// VEC: float4 accesses (all base pointers 16-byte aligned) with a scalar tail.  POLYAK: the target network's
+// copy of each parameter moves towards the new value in the same pass (target = tau p + (1 - tau) target,
+// 36 instead of 28 + 12 bytes per parameter and one launch instead of two).
+template <bool VEC, bool POLYAK>
 __global__ __launch_bounds__(256) void adam_dev_kernel(float* p, const float* __restrict__ g, float* m, float* v, long n,
-                                                       const float* __restrict__ hyper) {
+                                                       const float* __restrict__ hyper, float* t, float tau, float om) {
   AdamK k;
   k.step_size = hyper[0]; k.beta1 = hyper[1]; k.beta2 = hyper[2]; k.one_minus_b1 = hyper[3];
   k.one_minus_b2 = hyper[4]; k.bc2_sqrt = hyper[5]; k.eps = hyper[6]; k.gscale = hyper[7];
   const long stride = (long)gridDim.x * blockDim.x;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) adam_one(p[i], g[i], m[i], v[i], k);
+  const long first = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long done = 0;
+  if (VEC) {
+    const long n4 = n >> 2;
+    for (long i = first; i < n4; i += stride) {
+      float4 P = reinterpret_cast<float4*>(p)[i];
+      const float4 G = reinterpret_cast<const float4*>(g)[i];
+      float4 Mo = reinterpret_cast<float4*>(m)[i];
+      float4 V = reinterpret_cast<float4*>(v)[i];
+      adam_one(P.x, G.x, Mo.x, V.x, k);
+      adam_one(P.y, G.y, Mo.y, V.y, k);
+      adam_one(P.z, G.z, Mo.z, V.z, k);
+      adam_one(P.w, G.w, Mo.w, V.w, k);
+      reinterpret_cast<float4*>(p)[i] = P;
+      reinterpret_cast<float4*>(m)[i] = Mo;
+      reinterpret_cast<float4*>(v)[i] = V;
+      if (POLYAK) {
+        float4 T = reinterpret_cast<float4*>(t)[i];
+        T.x = polyak_one(T.x, P.x, tau, om);
+        T.y = polyak_one(T.y, P.y, tau, om);
+        T.z = polyak_one(T.z, P.z, tau, om);
+        T.w = polyak_one(T.w, P.w, tau, om);
+        reinterpret_cast<float4*>(t)[i] = T;
+      }
+    }
+    done = n4 << 2;
+  }
+  for (long i = done + first; i < n; i += stride) {
+    adam_one(p[i], g[i], m[i], v[i], k);
+    if (POLYAK) t[i] = polyak_one(t[i], p[i], tau, om);
+  }
 }
 
 __global__ __launch_bounds__(256) void polyak_kernel(float* t, const float* __restrict__ p, long n, float tau, float om, int vec) {
@@ -176,16 +212,16 @@ __global__ __launch_bounds__(256) void polyak_kernel(float* t, const float* __re
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
       const float4 P = reinterpret_cast<const float4*>(p)[i];
       float4 T = reinterpret_cast<float4*>(t)[i];
-      T.x = tau * P.x + om * T.x;
-      T.y = tau * P.y + om * T.y;
-      T.z = tau * P.z + om * T.z;
-      T.w = tau * P.w + om * T.w;
+      T.x = polyak_one(T.x, P.x, tau, om);
+      T.y = polyak_one(T.y, P.y, tau, om);
+      T.z = polyak_one(T.z, P.z, tau, om);
+      T.w = polyak_one(T.w, P.w, tau, om);
       reinterpret_cast<float4*>(t)[i] = T;
     }
     const long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) t[i] = tau * p[i] + om * t[i];
+    if (i < n) t[i] = polyak_one(t[i], p[i], tau, om);
   } else {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) t[i] = tau * p[i] + om * t[i];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) t[i] = polyak_one(t[i], p[i], tau, om);
   }
 }
 
@@ -311,13 +347,31 @@ int hhrl_adam_stage(float* hyper_dev, double lr, double beta1, double beta2, dou
   return launch_status("adam_stage_kernel");
 }
 
+static int adam_dev_launch(float* p, const float* g, float* m, float* v, long n, const float* hyper_dev, float* target,
+                           double tau, void* stream) {
+  hipStream_t st = as_stream(stream);
+  const bool vec = aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v) && (target == nullptr || aligned16(target));
+  ProfScope ps(target ? "adam_polyak_dev_kernel" : "adam_dev_kernel", st, 0.0, (target ? 36.0 : 28.0) * n);
+  const dim3 grid(stream_grid(vec ? (n + 3) / 4 : n));
+  const float ft = (float)tau, om = (float)(1.0 - tau);
+  if (vec && target) hipLaunchKernelGGL((adam_dev_kernel<true, true>), grid, dim3(256), 0, st, p, g, m, v, n, hyper_dev, target, ft, om);
+  else if (vec) hipLaunchKernelGGL((adam_dev_kernel<true, false>), grid, dim3(256), 0, st, p, g, m, v, n, hyper_dev, target, ft, om);
+  else if (target) hipLaunchKernelGGL((adam_dev_kernel<false, true>), grid, dim3(256), 0, st, p, g, m, v, n, hyper_dev, target, ft, om);
+  else hipLaunchKernelGGL((adam_dev_kernel<false, false>), grid, dim3(256), 0, st, p, g, m, v, n, hyper_dev, target, ft, om);
+  return launch_status("adam_dev_kernel");
+}
+
 int hhrl_adam_step_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper_dev, void* stream) {
   HHRL_REQUIRE(p && g && m && v && hyper_dev, "adam_step_dev: null pointer");
   HHRL_REQUIRE(n > 0, "adam_step_dev: n=%ld", n);
-  hipStream_t st = as_stream(stream);
-  ProfScope ps("adam_dev_kernel", st, 0.0, 28.0 * n);
-  hipLaunchKernelGGL(adam_dev_kernel, dim3(stream_grid(n)), dim3(256), 0, st, p, g, m, v, n, hyper_dev);
-  return launch_status("adam_dev_kernel");
+  return adam_dev_launch(p, g, m, v, n, hyper_dev, nullptr, 0.0, stream);
+}
+
+int hhrl_adam_polyak_step_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper_dev, float* target,
+                              double tau, void* stream) {
+  HHRL_REQUIRE(p && g && m && v && hyper_dev && target, "adam_polyak_step_dev: null pointer");
+  HHRL_REQUIRE(n > 0 && tau >= 0.0 && tau <= 1.0, "adam_polyak_step_dev: n=%ld tau=%g", n, tau);
+  return adam_dev_launch(p, g, m, v, n, hyper_dev, target, tau, stream);
 }
 
 int hhrl_polyak_update(float* target, const float* p, long n, double tau, void* stream) {

@@ -52,12 +52,18 @@ class FlatAdam:
         return (self.lr / bc1, self.beta1, self.beta2, 1.0 - self.beta1, 1.0 - self.beta2, math.sqrt(bc2), self.eps,
                 float(grad_scale))
 
-    def step_dev(self, hyper_ptr: int = 0) -> None:
+    def step_dev(self, hyper_ptr: int = 0, target=None, tau: float = 0.0) -> None:
         """Adam step with the scalars read from device memory (`hyper_ptr`, eight floats; default: the
-        buffer filled by `stage_next_step`)."""
-        _lib.check(self._lib.hhrl_adam_step_dev(
-            self.p.base_ptr, self.g.base_ptr, self.m.base_ptr, self.v.base_ptr, self.p.layout.size,
-            hyper_ptr or self._hyper_dev.data_ptr(), _lib.stream_ptr()))
+        buffer filled by `stage_next_step`).  `target` (a FlatBuffer of the same layout): the same launch
+        also moves the target network towards the new parameters, target = tau p + (1 - tau) target."""
+        hp = hyper_ptr or self._hyper_dev.data_ptr()
+        if target is None:
+            _lib.check(self._lib.hhrl_adam_step_dev(
+                self.p.base_ptr, self.g.base_ptr, self.m.base_ptr, self.v.base_ptr, self.p.layout.size, hp, _lib.stream_ptr()))
+        else:
+            _lib.check(self._lib.hhrl_adam_polyak_step_dev(
+                self.p.base_ptr, self.g.base_ptr, self.m.base_ptr, self.v.base_ptr, self.p.layout.size, hp,
+                target.base_ptr, float(tau), _lib.stream_ptr()))
 
     def commit_step(self) -> None:
         self.step_count += 1

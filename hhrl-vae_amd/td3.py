@@ -682,7 +682,12 @@ class TD3Learner:
         c.backward(B, both_heads=True, param_grads=True, lstms=False)
         self._lstm_backward([c.lstm_bwd_item(k, B) for k in range(n_str)], B)
         self._allreduce(c.opt.g)
-        c.opt.step_dev(P(st.hyper[0]))
+        # on a policy step the soft updates (:1361-1364 / 827-834) ride on the optimizer launches: nothing
+        # between a network's step and the end of the update reads its target
+        if policy:
+            c.opt.step_dev(P(st.hyper[0]), self.critic_target.params, fam.tau)
+        else:
+            c.opt.step_dev(P(st.hyper[0]))
 
         # -- delayed policy step: :1353-1366 / 811-838
         if policy:
@@ -703,12 +708,9 @@ class TD3Learner:
                 if a.lstm is not None:
                     self._lstm_backward([a.lstm_bwd_item(B)], B)
                 self._allreduce(a.opt.g)
-                a.opt.step_dev(P(st.hyper[1 + i]))
+                a.opt.step_dev(P(st.hyper[1 + i]), self.actor_targets[i].params, fam.tau)
                 if n + 1 < len(order):                # later actors see this actor's new policy
                     a.forward(B, obs[i][0], W, goal, W, P(cw.xu, c.act_cols[i]), c.D, inputs_done=True)
-            ops.polyak(self.critic_target.params, self.critic.params, fam.tau)
-            for a, t in zip(self.actors, self.actor_targets):
-                ops.polyak(t.params, a.params, fam.tau)
 
     @staticmethod
     def _actors_forward(nets, B: int, outs) -> None:

@@ -288,6 +288,11 @@ int hhrl_adam_step_dev(float* p, const float* g, float* m, float* v, long n, con
                        void* stream);
 /* target = tau*p + (1-tau)*target          (algorithm.py:323-326, 534-539, 827-834, 1163-1166, 1361-1364) */
 int hhrl_polyak_update(float* target, const float* p, long n, double tau, void* stream);
+/* hhrl_adam_step_dev followed by hhrl_polyak_update(target, p, ...) in one pass over the parameters: the
+ * optimizer step of a network (algorithm.py:320, 530, 824, 1159, 1357: `*_optimizer.step()`) and the soft
+ * update of its target (same lines as above) when no launch in between reads the target. */
+int hhrl_adam_polyak_step_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper_dev,
+                              float* target, double tau, void* stream);
 
 /* ------------------------------------------------------------- diagnostics
  * Per-launch timing with HIP events recorded on the launch stream (no

@@ -94,6 +94,39 @@ def test_argument_errors(env):
         L.check(lib.hhrl_fill(None, 4, 0.0, None))
 
 
+@pytest.mark.parametrize("n,off", [(5, 0), (1216898, 0), (38146, 0), (4099, 1)])
+def test_adam_polyak_fused_equals_two_launches(env, n, off):
+    """hhrl_adam_polyak_step_dev = hhrl_adam_step_dev followed by hhrl_polyak_update, bit for bit, on aligned
+    buffers (float4 body + scalar tail) and on a base that is not 16-byte aligned (scalar form)."""
+    lib, L, dev = env
+    g = torch.Generator().manual_seed(n)
+    mk = lambda: torch.randn(n + off, generator=g)
+    p0, gr, m0, v0, t0 = mk(), mk() * 0.1, mk() * 0.01, mk().abs() * 1e-3, mk()
+    hyper = torch.zeros(8, device=dev)
+    L.check(lib.hhrl_adam_stage(hyper.data_ptr(), 1e-3, 0.9, 0.999, 1e-8, 3, 1.0, L.stream_ptr()))
+    outs = []
+    for fused in (False, True):
+        p, grd, m, v, t = (x.to(dev) for x in (p0, gr, m0, v0, t0))
+        ptr = lambda x: x.data_ptr() + 4 * off
+        if fused:
+            L.check(lib.hhrl_adam_polyak_step_dev(ptr(p), ptr(grd), ptr(m), ptr(v), n, hyper.data_ptr(), ptr(t), 0.005, L.stream_ptr()))
+        else:
+            L.check(lib.hhrl_adam_step_dev(ptr(p), ptr(grd), ptr(m), ptr(v), n, hyper.data_ptr(), L.stream_ptr()))
+            L.check(lib.hhrl_polyak_update(ptr(t), ptr(p), n, 0.005, L.stream_ptr()))
+        outs.append([x.cpu() for x in (p, m, v, t)])
+    for a, b, name in zip(outs[0], outs[1], "pmvt"):
+        assert torch.equal(a, b), name
+    assert not torch.equal(outs[0][3][off:], t0[off:]) and not torch.equal(outs[0][0][off:], p0[off:])
+    if off:
+        assert all(float(x[0]) == float(y[0]) for x, y in zip(outs[1], (p0, m0, v0, t0)))
+    # and the step itself against the reference formula (torch.optim.Adam semantics at step 3)
+    ref_m = 0.9 * m0[off:].double() + 0.1 * gr[off:].double()
+    ref_v = 0.999 * v0[off:].double() + 0.001 * gr[off:].double() ** 2
+    ref_p = p0[off:].double() - (1e-3 / (1 - 0.9 ** 3)) * ref_m / (ref_v.sqrt() / (1 - 0.999 ** 3) ** 0.5 + 1e-8)
+    scaled_close("p", outs[1][0][off:].numpy(), ref_p.numpy(), rtol=1e-5, atol_rel=1e-6)
+    scaled_close("t", outs[1][3][off:].numpy(), (0.005 * ref_p + 0.995 * t0[off:].double()).numpy(), rtol=1e-5, atol_rel=1e-6)
+
+
 def test_adam_beyond_the_caches(env):
     """Buffers of 64 Mi + 5 parameters take the non-temporal form of the Adam kernel (plus the scalar tail):
     two steps against torch.optim.Adam on the CPU."""
