@@ -47,3 +47,17 @@ def allreduce_sum_(flat: torch.Tensor, group) -> torch.Tensor:
         import torch.distributed as dist
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat
+
+
+def broadcast_ints(values, group, device=None):
+    """The group's first rank's `values` (a short sequence of ints) on every rank: decisions that the
+    ranks draw from their own host generators but must take alike, such as the order in which a
+    multi-actor update steps its actors (algorithm.py:809) — each actor's step has an all-reduce of its
+    own, so the ranks have to walk the actors in the same order.  No-op without a group."""
+    vals = [int(v) for v in values]
+    if group is None:
+        return vals
+    import torch.distributed as dist
+    t = torch.tensor(vals, dtype=torch.int64, device=device)
+    dist.broadcast(t, src=dist.get_global_rank(group, 0), group=group)
+    return [int(v) for v in t.cpu().tolist()]

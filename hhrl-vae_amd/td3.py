@@ -517,6 +517,9 @@ class TD3Learner:
         if policy:
             if order is None:
                 order = np.random.permutation(n_act) if n_act > 1 else [0]
+                if self.group is not None and n_act > 1:          # every rank walks the actors in rank 0's order
+                    from . import dist as hdist
+                    order = hdist.broadcast_ints(order, self.group, self.device)
             order = tuple(int(i) for i in order)
             if sorted(order) != list(range(n_act)):
                 raise ValueError("order must be a permutation of range(%d)" % n_act)

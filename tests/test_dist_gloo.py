@@ -71,6 +71,10 @@ def _worker(rank, world, port, out_dir):
     flat = torch.cat([x_.reshape(-1) for x_ in cg])
     hdist.allreduce_sum_(flat, group)
     res["td3_grad"] = flat.numpy()
+    # ---- the actor order of a multi-actor update: drawn per rank, rank 0's taken by all
+    mine = np.random.RandomState(100 + rank).permutation(3)
+    res["order_mine"] = mine
+    res["order_agreed"] = np.asarray(hdist.broadcast_ints(mine, group))
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **res)
     dist.barrier()
     dist.destroy_process_group()
@@ -86,7 +90,10 @@ def test_world2_matches_single_process(tmp_path):
     r0 = np.load(os.path.join(str(tmp_path), "rank0.npz"))
     r1 = np.load(os.path.join(str(tmp_path), "rank1.npz"))
     for k in r0.files:                                     # replicas stay identical
-        assert np.array_equal(r0[k], r1[k]), k
+        if k != "order_mine":
+            assert np.array_equal(r0[k], r1[k]), k
+    assert not np.array_equal(r0["order_mine"], r1["order_mine"])                 # the ranks drew different orders
+    assert np.array_equal(r1["order_agreed"], r0["order_mine"]) and sorted(r1["order_agreed"]) == [0, 1, 2]
     g, N = 4, 5
     init = {k: torch.from_numpy(v) for k, v in gen.gen_state(O.vae_param_shapes(g), 5).items()}
     x = torch.from_numpy(gen.gen_lanes(10, N, 6))

@@ -64,3 +64,32 @@ def test_td3_one_rank_group_matches_single_device(group):
     for (na, sa), (nb, sb) in zip(a.state_dicts().items(), b.state_dicts().items()):
         for k in sa:
             assert torch.equal(sa[k], sb[k]), (na, k)
+
+
+def test_multi_actor_group_update_draws_one_order(group):
+    """HATD3Triple with a process group and no injected actor order: the order is drawn from numpy's global
+    generator as in the reference (algorithm.py:809) and passed through the group's broadcast, so that every
+    rank steps (and all-reduces) the actors in the same sequence; with one rank the result is the single-device
+    update under the same numpy seed, bit for bit apart from the float atomics of the weight-gradient kernels."""
+    from hhrl_vae_amd.algorithm import HATD3Triple
+    from test_gpu_kernels import scaled_close
+    cfg = gen.light_cfg(o=(5, 6, 7), T=4, s=8, a=(1, 2, 3), actor_h=(12, 10), critic_h=(14, 12), batch=8, cap=32)
+    a, b = HATD3Triple(cfg, device="cuda:0", seed=5), HATD3Triple(cfg, device="cuda:0", seed=5, group=group)
+    rows = np.random.RandomState(2).uniform(0, 1, size=(32, a.fam.row_width))
+    for net in (a, b):
+        net.memory[:] = rows
+        net.pointer = 32
+    rs = np.random.RandomState(3)
+    seen = []
+    for step in range(6):
+        idx = rs.randint(0, 32, size=8)
+        noise = [rs.standard_normal((8, d)).astype(np.float32) for d in a.fam.a_dims]
+        for net in (a, b):
+            np.random.seed(50 + step)
+            net.learn(None, indices=idx, noise=noise)
+        np.random.seed(50 + step)
+        seen.append(tuple(np.random.permutation(3)))
+    assert len(set(seen)) > 1                                  # several different orders were exercised
+    for (na, sa), (nb, sb) in zip(a.state_dicts().items(), b.state_dicts().items()):
+        for k in sa:
+            scaled_close(na + "/" + k, sb[k].cpu().numpy(), sa[k].cpu().numpy(), rtol=1e-5, atol_rel=1e-6)
