@@ -1,6 +1,7 @@
 // Shared helpers for the gfx950 kernels of libhhrl_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdarg>
 #include <cstdio>
 
@@ -84,11 +85,26 @@ inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 // work (flops, bytes) of that launch; hhrl_prof_report() aggregates by name.
 bool prof_on();
 struct ProfScope {
-  ProfScope(const char* name, hipStream_t st, double flops, double bytes);
+  // own_launch: the events are not recorded around the launch but handed to it (launch_timed below), so that
+  // they carry the dispatch's own begin and end timestamps, the interval a kernel trace reports
+  ProfScope(const char* name, hipStream_t st, double flops, double bytes, bool own_launch = false);
   ~ProfScope();
+  hipEvent_t beg() const;
+  hipEvent_t end() const;
   int slot;
   hipStream_t st;
+  bool own;
 };
+
+// Launch of `kernel` that, while profiling is on, is stamped with its own start and stop events.
+template <typename... KArgs, typename... Args>
+inline void launch_timed(const ProfScope& ps, void (*kernel)(KArgs...), dim3 grid, dim3 block, unsigned lds, hipStream_t st,
+                         Args... args) {
+  if (ps.slot >= 0 && ps.own)
+    hipExtLaunchKernelGGL(kernel, grid, block, lds, st, ps.beg(), ps.end(), 0, static_cast<KArgs>(args)...);
+  else
+    hipLaunchKernelGGL(kernel, grid, block, lds, st, static_cast<KArgs>(args)...);
+}
 
 // Internal GEMM front door (gemm.hip):  C[i][j] (op)= sum_k A(i,k) * B(k,j)
 //   A(i,k) = A[i*a_si + k*a_sk],  B(k,j) = B[k*b_sk + j*b_sj]

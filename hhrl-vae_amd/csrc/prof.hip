@@ -33,20 +33,33 @@ static hipEvent_t get_event() {
   return e;
 }
 
-ProfScope::ProfScope(const char* name, hipStream_t s, double flops, double bytes) : slot(-1), st(s) {
+ProfScope::ProfScope(const char* name, hipStream_t s, double flops, double bytes, bool own_launch)
+    : slot(-1), st(s), own(own_launch) {
   if (!g_prof) return;
   std::lock_guard<std::mutex> lk(g_mu);
   ProfRec r{name, get_event(), get_event(), flops, bytes};
   if (!r.beg || !r.end) return;
-  (void)hipEventRecord(r.beg, st);
+  if (!own) (void)hipEventRecord(r.beg, st);
   slot = (int)g_recs.size();
   g_recs.push_back(r);
 }
 
 ProfScope::~ProfScope() {
-  if (slot < 0) return;
+  if (slot < 0 || own) return;
   std::lock_guard<std::mutex> lk(g_mu);
   (void)hipEventRecord(g_recs[slot].end, st);
+}
+
+hipEvent_t ProfScope::beg() const {
+  if (slot < 0) return nullptr;
+  std::lock_guard<std::mutex> lk(g_mu);
+  return g_recs[slot].beg;
+}
+
+hipEvent_t ProfScope::end() const {
+  if (slot < 0) return nullptr;
+  std::lock_guard<std::mutex> lk(g_mu);
+  return g_recs[slot].end;
 }
 
 }  // namespace hhrl

@@ -1742,11 +1742,11 @@ static int vae_step_impl(float* params, float* grads, float* m, float* v, const 
 
   const double lane_macs = 16.0 * 2 * N + 512 + 4096 + 8192 + 128.0 * g + 128.0 * g + 4096;
   {
-    ProfScope ps("vae_lane_forward_kernel", st, 2.0 * lane_macs * B, 4.0 * B * (2.0 * N + g + 32));
+    ProfScope ps("vae_lane_forward_kernel", st, 2.0 * lane_macs * B, 4.0 * B * (2.0 * N + g + 32), true);
     if (lane_threads == 512)
-      hipLaunchKernelGGL(vae_lane_forward_kernel<512>, dim3(nlane), dim3(512), LN_LDS_FLOATS * 4, st, la);
+      launch_timed(ps, vae_lane_forward_kernel<512>, dim3(nlane), dim3(512), LN_LDS_FLOATS * 4, st, la);
     else
-      hipLaunchKernelGGL(vae_lane_forward_kernel<256>, dim3(nlane), dim3(256), LN_LDS_FLOATS * 4, st, la);
+      launch_timed(ps, vae_lane_forward_kernel<256>, dim3(nlane), dim3(256), LN_LDS_FLOATS * 4, st, la);
     HHRL_TRY(launch_status("vae_lane_forward_kernel"));
   }
 
@@ -1770,8 +1770,8 @@ static int vae_step_impl(float* params, float* grads, float* m, float* v, const 
   {
     // the algorithm's forward + input-gradient + weight-gradient products of loc/func.0/func.2/func.4:
     // 3 * 2 * 12352 flop per car (func.0's share is not executed per car here, see the kernel's header)
-    ProfScope ps("vae_car_fwd_bwd_kernel", st, 6.0 * (8192 + 4096 + 32 + 32) * rows, 4.0 * (2.0 * rows + 64.0 * B));
-    hipLaunchKernelGGL(vae_car_fwd_bwd_kernel, dim3(ncar), dim3(CAR_THREADS), CAR_LDS_FLOATS * 4, st, ca);
+    ProfScope ps("vae_car_fwd_bwd_kernel", st, 6.0 * (8192 + 4096 + 32 + 32) * rows, 4.0 * (2.0 * rows + 64.0 * B), true);
+    launch_timed(ps, vae_car_fwd_bwd_kernel, dim3(ncar), dim3(CAR_THREADS), CAR_LDS_FLOATS * 4, st, ca);
     HHRL_TRY(launch_status("vae_car_fwd_bwd_kernel"));
   }
   // per-car gradient slabs summed by extra workgroups of the per-lane backward launch, on CUs it leaves idle
@@ -1790,21 +1790,21 @@ static int vae_step_impl(float* params, float* grads, float* m, float* v, const 
   const bool co = cr.n_blocks > 0;
   const long skip_lo = co ? car_lo : 0, skip_mid = co ? f0_lo : 0, skip_back = co ? f0_hi : 0, skip_hi = co ? ((car_hi + 63) / 64) * 64 : 0;
   {
-    ProfScope ps("vae_lane_backward_kernel", st, 4.0 * lane_macs * B, 4.0 * B * (2.0 * N + g + 32));
+    ProfScope ps("vae_lane_backward_kernel", st, 4.0 * lane_macs * B, 4.0 * B * (2.0 * N + g + 32), true);
     if (nlane >= la.tiles && lane_threads == 512)
-      hipLaunchKernelGGL((vae_lane_backward_kernel<true, 512>), dim3(nlane + cr.n_blocks), dim3(512), LN_LDS_FLOATS * 4, st, la, cr);
+      launch_timed(ps, (vae_lane_backward_kernel<true, 512>), dim3(nlane + cr.n_blocks), dim3(512), LN_LDS_FLOATS * 4, st, la, cr);
     else if (nlane >= la.tiles)
-      hipLaunchKernelGGL((vae_lane_backward_kernel<true, 256>), dim3(nlane), dim3(256), LN_LDS_FLOATS * 4, st, la, cr);
+      launch_timed(ps, (vae_lane_backward_kernel<true, 256>), dim3(nlane), dim3(256), LN_LDS_FLOATS * 4, st, la, cr);
     else
-      hipLaunchKernelGGL((vae_lane_backward_kernel<false, 256>), dim3(nlane), dim3(256), LN_LDS_FLOATS * 4, st, la, cr);
+      launch_timed(ps, (vae_lane_backward_kernel<false, 256>), dim3(nlane), dim3(256), LN_LDS_FLOATS * 4, st, la, cr);
     HHRL_TRY(launch_status("vae_lane_backward_kernel"));
   }
   {
     // reads every slab column once (per-car columns from ncar slabs, the others from nlane), writes the gradient
     const double slab_floats = (cr.n_blocks > 0 ? 256.0 * ncar : (double)(car_hi - car_lo - 8192 + 128) * ncar) +
                                (double)(n_flat - (car_hi - car_lo) + 4096) * nlane;
-    ProfScope ps("vae_reduce_grads_kernel", st, 0.0, 4.0 * (slab_floats + n_flat * (adam ? 7.0 : 1.0)));
-    hipLaunchKernelGGL(vae_reduce_grads_kernel, dim3(ceil_div(n_flat, 64)), dim3(256), 0, st, w.slab, n_flat, ncar, nlane,
+    ProfScope ps("vae_reduce_grads_kernel", st, 0.0, 4.0 * (slab_floats + n_flat * (adam ? 7.0 : 1.0)), true);
+    launch_timed(ps, vae_reduce_grads_kernel, dim3(ceil_div(n_flat, 64)), dim3(256), 0, st, w.slab, n_flat, ncar, nlane,
                        car_lo, car_hi, f0_lo, b0_off, w.aux + 128, co ? w.aux + 192 : nullptr, skip_lo, skip_mid, skip_back, skip_hi, grads, w.loss_part, w.kl_part, loss, adam ? params : nullptr, m, v,
                        adam ? *adam : AdamK());
     HHRL_TRY(launch_status("vae_reduce_grads_kernel"));
