@@ -142,7 +142,7 @@ def test_vae_full_size_vs_oracle(B, N, g):
         # Weight gradients here are sums over B*N rows of terms that largely cancel, and a ReLU whose
         # input rounds to the other side of zero moves a whole term.  Both fp32 evaluations (this one and
         # the CPU oracle) land up to ~2e-4 of a tensor's largest entry away from the fp64 value on single
-        # elements (tools/vae_accuracy.py prints the per-tensor distances: e.g. 2.1e-7 for the oracle on
+        # elements (tests/diag_vae_accuracy.py prints the per-tensor distances: e.g. 2.1e-7 for the oracle on
         # decoder.func.0.weight at B=4096, N=7, largest entry 1.1e-3).  The absolute floor is therefore
         # 10 * 2^-24 * sqrt(rows) of the tensor's largest entry (2.1e-4 at 122,880 rows), or three times
         # the fp32 oracle's own worst distance from the fp64 value on that tensor, whichever is larger;
