@@ -42,6 +42,15 @@ def shuffle_chunks(chunks: List[list], rng: Optional[random.Random] = None) -> L
     return out
 
 
+def prepare_chunks(chunks: Iterable, device="cuda") -> List:
+    """Each chunk as an fp32 device tensor [B, N, 2], converted once.  The reference turns a chunk's nested
+    lists into a tensor inside every `learn` call (algorithm.py:93), i.e. once per chunk per latent size;
+    the conversion costs more host time than the whole training step takes on the GPU."""
+    import numpy as np
+    import torch
+    return [torch.from_numpy(np.asarray(c, dtype=np.float32)).to(device) for c in chunks]
+
+
 def train_one_pass(encoder: Encoder, chunks: Iterable, eps_list: Optional[Sequence] = None,
                    on_step: Optional[Callable[[int, float], None]] = None, sync_every: int = 1) -> List[float]:
     """VAE_train.py:65-68: one optimizer step per chunk, loss logged per step.
@@ -81,6 +90,7 @@ def train_all(dataset: Dict[str, list], goal_dims: Sequence[int] = (2, 4, 8, 16)
     every latent size on a freshly initialised model; each model is saved as
     `<save_dir>/encoder_dim_<g>` (+ `_enc`, `_dec`, `_encoder_optimizer`)."""
     shuffled = shuffle_chunks(chunk_dataset(dataset, batch_size), shuffle_rng)
+    shuffled = prepare_chunks(shuffled)              # the same chunks are replayed for every latent size
     out = {}
     for g in goal_dims:
         enc = Encoder(2, g)

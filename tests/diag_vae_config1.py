@@ -8,7 +8,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", 
 import numpy as np, torch
 import gen, hhrl_oracle as O
 from hhrl_vae_amd.algorithm import Encoder
-from hhrl_vae_amd.vae_train import chunk_dataset, shuffle_chunks, train_one_pass
+from hhrl_vae_amd.vae_train import chunk_dataset, prepare_chunks, shuffle_chunks, train_one_pass
 
 rng = np.random.default_rng(3407)
 dataset = {}
@@ -28,8 +28,10 @@ for g in (2, 4, 8, 16):
         dt = time.perf_counter() - t0
         print("g=%d sync_every=%d: %.1f ms per pass, %.1f us/step, final loss %.4f" % (g, se, 1e3 * dt, 1e6 * dt / len(chunks), losses[-1]))
     # pre-converted device tensors: the kernels alone
-    dev_chunks = [torch.tensor(c, dtype=torch.float32).cuda() for c in chunks]
+    t0 = time.perf_counter()
+    dev_chunks = prepare_chunks(chunks)
     torch.cuda.synchronize()
+    print("g=%d prepare_chunks: %.1f ms once (%.1f us per chunk)" % (g, 1e3 * (time.perf_counter() - t0), 1e6 * (time.perf_counter() - t0) / len(chunks)))
     t0 = time.perf_counter()
     train_one_pass(enc, dev_chunks, sync_every=64)
     torch.cuda.synchronize()

@@ -99,6 +99,27 @@ def test_vae_golden_batch_loop():
     params_close("final", _np(e.state_dict()), sub(fx, "final/param"), len(order))
 
 
+def test_vae_train_all_converts_chunks_once(tmp_path):
+    """train_all (VAE_train.py:55-69): the shuffled chunks are turned into device tensors once and replayed
+    for every latent size; each model's loss sequence is what a fresh model gets from the same chunks as
+    nested lists, bit for bit, and the reference's three files per model are written."""
+    import os
+    import random
+    from hhrl_vae_amd.algorithm import Encoder
+    from hhrl_vae_amd.vae_train import chunk_dataset, shuffle_chunks, train_all, train_one_pass
+    rs = np.random.RandomState(9)
+    dataset = {str(n): rs.uniform(0, 1, size=(cnt, n, 2)).tolist() for n, cnt in ((1, 70), (5, 64), (17, 30))}
+    out = train_all(dataset, goal_dims=(2, 8), batch_size=64, save_dir=str(tmp_path), shuffle_rng=random.Random(4), sync_every=8)
+    chunks = shuffle_chunks(chunk_dataset(dataset, 64), random.Random(4))
+    assert [len(c) for c in chunks].count(6) == 1 and len(chunks) == 4              # 64 + 6, 64, 30
+    for g in (2, 8):
+        enc, losses = out[g]
+        assert len(losses) == len(chunks) and enc.opt.step_count == len(chunks)
+        assert losses == train_one_pass(Encoder(2, g), chunks)
+        for suf in ("_enc", "_dec", "_encoder_optimizer"):
+            assert os.path.exists(os.path.join(str(tmp_path), "encoder_dim_%d%s" % (g, suf)))
+
+
 def adam_conditioned_close(name, got_p, want_p, want_g, lr, g_floor, rtol=1e-4):
     """Parameters after an Adam step.  Adam normalises the gradient, so an
     early step moves a weight by about lr * g/|g|: a gradient element known
