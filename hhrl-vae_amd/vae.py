@@ -155,7 +155,11 @@ class Encoder:
         # step's slot, valid for the next LOSS_RING - 1 steps, instead of copying it
         self._loss_ring = ops.dev_zeros(self.LOSS_RING, device=self.device)
         self._loss_slot = 0
-        self._loss = self._loss_ring[0:1]
+        # views of every slot made once: a step then pays no tensor construction for its loss
+        self._loss_views = [self._loss_ring[i:i + 1] for i in range(self.LOSS_RING)]
+        self._loss_scalars = [self._loss_ring[i] for i in range(self.LOSS_RING)]
+        self._loss_ptrs = [v.data_ptr() for v in self._loss_views]
+        self._loss = self._loss_views[0]
         self._rng = torch.Generator(device=self.device)
         self._rng.manual_seed(3407)
         self._eps_pool = None           # reparameterisation noise is drawn EPS_POOL floats at a time
@@ -219,13 +223,29 @@ class Encoder:
             # a fresh tensor each time: slices handed out earlier may still be queued on the stream
             self._eps_pool = torch.randn(self.EPS_POOL, generator=self._rng, device=self.device, dtype=torch.float32)
             self._eps_used = 0
+            self._eps_base = self._eps_pool.data_ptr()
         e = self._eps_pool[self._eps_used:self._eps_used + n].view(B, g)
         self._eps_used += (n + 3) & ~3          # keep slices 16-byte aligned
         return e
 
+    def _draw_eps_ptr(self, B: int, g: int):
+        """As _draw_eps for the fused step: (device address of the [B, g] block, the tensor that owns it),
+        without building a view per step."""
+        n = B * g
+        if n > self.EPS_POOL // 4:
+            e = torch.randn((B, g), generator=self._rng, device=self.device, dtype=torch.float32)
+            return e.data_ptr(), e
+        if self._eps_pool is None or self._eps_used + n > self.EPS_POOL:
+            self._eps_pool = torch.randn(self.EPS_POOL, generator=self._rng, device=self.device, dtype=torch.float32)
+            self._eps_used = 0
+            self._eps_base = self._eps_pool.data_ptr()
+        ptr = self._eps_base + 4 * self._eps_used
+        self._eps_used += (n + 3) & ~3
+        return ptr, self._eps_pool
+
     def _next_loss_slot(self) -> torch.Tensor:
         self._loss_slot = (self._loss_slot + 1) % self.LOSS_RING
-        self._loss = self._loss_ring[self._loss_slot:self._loss_slot + 1]
+        self._loss = self._loss_views[self._loss_slot]
         return self._loss
 
     # ------------------------------------------------------------ training
@@ -240,7 +260,10 @@ class Encoder:
             raise ValueError("data must be [B, N, 2] with B, N >= 1, got %s" % (tuple(x.shape),))
         B, N = int(x.shape[0]), int(x.shape[1])
         g = self.goal_dim
-        if eps is None:
+        eps_ptr = 0
+        if eps is None and self.fused:
+            eps_ptr, eps = self._draw_eps_ptr(B, g)
+        elif eps is None:
             eps = self._draw_eps(B, g)
         else:
             eps = torch.as_tensor(eps, dtype=torch.float32).to(self.device).contiguous()
@@ -256,21 +279,23 @@ class Encoder:
                 n = lib.hhrl_vae_workspace_floats(B, N, g, self.layout.size)
                 ws = self._fused_ws[(B, N)] = ops.dev_zeros(n, device=self.device)
             scale = 1.0 / float(recon_count if recon_count is not None else B * N)
-            loss = self._next_loss_slot()
+            self._next_loss_slot()
+            if not eps_ptr:
+                eps_ptr = P(eps)
             # data-parallel: the loss lands right behind the gradient so that one all-reduce carries both
-            loss_ptr = self.opt.g.tail_ptr if _loss_to_tail else P(loss)
+            loss_ptr = self.opt.g.tail_ptr if _loss_to_tail else self._loss_ptrs[self._loss_slot]
             if _adam:
                 # forward, backward and the optimizer step in one call (single device)
                 o = self.opt
                 o.step_count += 1
                 check(lib.hhrl_vae_learn_step(self.params.base_ptr, o.g.base_ptr, o.m.base_ptr, o.v.base_ptr,
-                                              self._offsets, self.layout.size, P(x), P(eps), B, N, g, scale,
+                                              self._offsets, self.layout.size, P(x), eps_ptr, B, N, g, scale,
                                               o.lr, o.beta1, o.beta2, o.eps, o.step_count, loss_ptr, P(ws), st))
             else:
                 check(lib.hhrl_vae_train_step(self.params.base_ptr, self.opt.g.base_ptr, self._offsets,
-                                              self.layout.size, P(x), P(eps), B, N, g, scale, loss_ptr, P(ws), st))
+                                              self.layout.size, P(x), eps_ptr, B, N, g, scale, loss_ptr, P(ws), st))
             self._keep = (x, eps)
-            return loss[0]
+            return self._loss_scalars[self._loss_slot]
         w = self._ws(B, N)
         M = w.M
         self.opt.zero_grad()                                            # algorithm.py:98
@@ -322,8 +347,8 @@ class Encoder:
             if self.fused:
                 loss = self.loss_and_grads(x, eps, recon_count=global_count, _loss_to_tail=True)
                 hdist.allreduce_sum_(g.full, self.group)                # one flat bucket: gradient + loss, SUM
-                loss = self._loss[0]
-                self.opt.step(copy=(g.tail_ptr, self._loss.data_ptr()))  # :106, and the summed loss into its slot
+                loss = self._loss_scalars[self._loss_slot]
+                self.opt.step(copy=(g.tail_ptr, self._loss_ptrs[self._loss_slot]))  # :106, and the summed loss into its slot
             else:
                 loss = self.loss_and_grads(x, eps, recon_count=global_count)
                 hdist.allreduce_sum_(g.data, self.group)
