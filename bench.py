@@ -112,14 +112,22 @@ def agent_update_rates(device, steps: int) -> dict:
             forms = net.launch_forms()
             if it >= 30 and len(forms) == 1 + n_orders and "tuning" not in forms.values():
                 break
+        # ... and until the device has been busy with this update for half a second: the update chains that
+        # are bound by the GPU (device-resident replay) are measured at the clocks the chip settles on
         torch.cuda.synchronize()
+        t_w, n_w = time.perf_counter(), 0
+        while time.perf_counter() - t_w < 0.5:
+            net.learn()
+            n_w += 1
+        torch.cuda.synchronize()
+        n_timed = max(steps, int(0.25 * n_w / (time.perf_counter() - t_w)))          # at least a quarter of a second
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(n_timed):
             net.learn()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        out[name] = {"minibatches_per_s": steps / dt, "ms_per_update": 1e3 * dt / steps,
-                     "rows_per_s": steps * net.batch_size / dt}
+        out[name] = {"minibatches_per_s": n_timed / dt, "ms_per_update": 1e3 * dt / n_timed,
+                     "rows_per_s": n_timed * net.batch_size / dt, "updates_timed": n_timed}
         # one policy evaluation as the agents call it every control step (host round trip included)
         fam = net.fam
         o = rows[0, :fam.streams[0].width]

