@@ -124,7 +124,7 @@ def test_four_intersections_stream_matches_oracle():
 
 
 def test_four_intersections_batched_inference_same_values():
-    """The batched inference calls (eight lanes per `encode_lanes`, both advised speeds per `decode_host`)
+    """The batched inference calls (eight lanes per `encode_lanes`, the advised speeds of a light's head CAVs per `decode_host`, their actions per `policy`)
     feed the stream the same values as one call per lane / location: same call counts, encodings and
     advised speeds bit-identical while the two runs' inputs are (until the first update), and within 2e-6 of
     the tensor's scale throughout.  Actions, replay rows and parameters are held to the bars of the oracle
@@ -140,7 +140,7 @@ def test_four_intersections_batched_inference_same_values():
         torch.cuda.synchronize()
         outs.append((c, tr, mgr.memory.copy(), wrk.memory.copy(), mgr.state_dicts(), wrk.state_dicts(), wrk.total_it))
     (c0, t0, mm0, wm0, ms0, ws0, steps), (c1, t1, mm1, wm1, ms1, ws1, _) = outs
-    assert c1["encode"] * 16 == c0["encode"] and c1["decode"] * 2 == c0["decode"]
+    assert c1["encode"] * 16 == c0["encode"] and c1["decode"] * 4 < c0["decode"] and c1["choose_worker"] * 2 < c0["choose_worker"]
     assert c0["learn_worker"] == c1["learn_worker"] > 0 and c0["learn_manager"] == c1["learn_manager"] > 0
     for key in t0:
         scaled_close(key, np.stack(t1[key]), np.stack(t0[key]), atol_rel=2e-6 if key in ("enc", "adv") else 2e-4)

@@ -101,8 +101,8 @@ def run(encoder, manager, worker, stream: Stream, seconds: int, seed: int = 0, v
     time spent inside each kind of call.  `trace`, if given, collects the values that flow between the
     calls (encodings, advised speeds, actions) for comparison between implementations.  `batched` uses
     the calls the reference does not have: the eight lanes of a light in one `encode_lanes` call (shared
-    by manager and worker, which encode the same lanes) and the two advised speeds of a CAV in one
-    `decode_host` call; the values are the same."""
+    by manager and worker, which encode the same lanes), the advised speeds of all head CAVs of a light in
+    one `decode_host` call and their actions in one `policy` call; the values are the same."""
     rng = np.random.RandomState(seed)
     g2 = 2 * encoder.goal_dim
     T = manager.fam.streams[0].T
@@ -195,6 +195,10 @@ def run(encoder, manager, worker, stream: Stream, seconds: int, seed: int = 0, v
                 cnt["encode"] += N_LANES
             if goal is not None:
                 goal_state[L] = np.clip(lane_state + goal.reshape(N_LANES, -1), 0, 1)       # agent.py:766-772
+            # pass 1, per head CAV in lane order: observation and every random draw of its step (decoder noise,
+            # the uniform action while the replay fills, exploration noise) -- none depends on a network output
+            cavs = []
+            will_store = 0
             for l in range(N_LANES):
                 cav = stream.head_cav(t, L, l)
                 if cav is None:
@@ -204,25 +208,49 @@ def run(encoder, manager, worker, stream: Stream, seconds: int, seed: int = 0, v
                 b["obs"].append(ov)
                 eps = rng.standard_normal((2, encoder.goal_dim)).astype(np.float32)
                 nxt = (ov[0] * LANE_LENGTH + ov[1] * MAX_SPEED) / LANE_LENGTH
-                if batched:
-                    both = timed("decode", encoder.decode_host, np.stack([goal_state[L][l]] * 2), [[ov[0]], [nxt]], eps)
-                    adv0, adv1 = both[0].tolist(), both[1].tolist()
-                    cnt["decode"] += 1
-                else:
-                    adv0 = timed("decode", encoder.decode, goal_state[L][l], [ov[0]], eps=eps[0]).flatten().tolist()
-                    adv1 = timed("decode", encoder.decode, goal_state[L][l], [nxt], eps=eps[1]).flatten().tolist()
+                # the CAVs before this one have stored their transitions by the time it chooses (agent.py:820, 845)
+                explore = worker.pointer + will_store < worker.learn_begin
+                rand = rng.random_sample(worker.fam.a_dims[0]) * 2 - 1 if explore else None
+                noise_v = rng.normal(0, var, size=(worker.fam.a_dims[0],))
+                will_store += len(b["obs"]) >= 2
+                cavs.append({"l": l, "cav": cav, "ov": ov, "b": b, "eps": eps, "nxt": nxt, "rand": rand, "noise": noise_v})
+            # advised speeds at the CAV's location and at its next one (agent.py:809-811)
+            if batched and cavs:
+                goals2 = np.repeat(np.stack([goal_state[L][c["l"]] for c in cavs]), 2, axis=0)
+                locs2 = np.array([[c["ov"][0]] if k == 0 else [c["nxt"]] for c in cavs for k in (0, 1)])
+                both = timed("decode", encoder.decode_host, goals2, locs2, np.concatenate([c["eps"] for c in cavs]))
+                cnt["decode"] += 1
+                for i, c in enumerate(cavs):
+                    c["adv"] = both[2 * i].tolist() + both[2 * i + 1].tolist()
+            else:
+                for c in cavs:
+                    gs = goal_state[L][c["l"]]
+                    adv0 = timed("decode", encoder.decode, gs, [c["ov"][0]], eps=c["eps"][0]).flatten().tolist()
+                    adv1 = timed("decode", encoder.decode, gs, [c["nxt"]], eps=c["eps"][1]).flatten().tolist()
                     cnt["decode"] += 2
-                tr["adv"].append(np.array(adv0 + adv1))
-                gv = goal_state[L][l].flatten().tolist() + adv0 + adv1
-                b["goal"].append(gv)
-                if worker.pointer < worker.learn_begin:
-                    av = rng.random_sample(worker.fam.a_dims[0]) * 2 - 1
-                else:
-                    av = timed("choose", worker.choose_action, [ov], gv)
+                    c["adv"] = adv0 + adv1
+            for c in cavs:
+                tr["adv"].append(np.array(c["adv"]))
+                c["gv"] = goal_state[L][c["l"]].flatten().tolist() + c["adv"]
+                c["b"]["goal"].append(c["gv"])
+            # the policy for the CAVs that do not act at random (agent.py:820-826)
+            acting = [c for c in cavs if c["rand"] is None]
+            if batched and acting:
+                acts = timed("choose", worker.policy, np.array([c["ov"] for c in acting]), np.array([c["gv"] for c in acting]))
+                cnt["choose_worker"] += 1
+                for c, a in zip(acting, np.asarray(acts)):
+                    c["act"] = np.asarray(a, dtype=np.float64).reshape(-1)
+            else:
+                for c in acting:
+                    c["act"] = timed("choose", worker.choose_action, [c["ov"]], c["gv"])
                     cnt["choose_worker"] += 1
-                av = np.clip(rng.normal(0, var, size=av.shape) + av, -1, 1)
+            # pass 2: exploration noise, reward, transition (agent.py:824-851)
+            for c in cavs:
+                l, b, ov = c["l"], c["b"], c["ov"]
+                av = c["rand"] if c["rand"] is not None else c["act"]
+                av = np.clip(c["noise"] + av, -1, 1)
                 tr["a_worker"].append(np.array(av))
-                r = 0.5 * stream.cav_reward(t, cav) - 0.5 * float(np.sqrt(np.sum((goal_state[L][l] - lane_state[l]) ** 2)))
+                r = 0.5 * stream.cav_reward(t, c["cav"]) - 0.5 * float(np.sqrt(np.sum((goal_state[L][l] - lane_state[l]) ** 2)))
                 b["reward"].append(r)
                 if len(b["obs"]) >= 2:
                     timed("store", worker.store_transition, np.array(b["obs"][-2]).flatten(), ov[2], b["goal"][-2],
