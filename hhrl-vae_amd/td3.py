@@ -959,6 +959,11 @@ class HATD3Double(_FlatReplayMixin, TD3Learner):
     def choose_goal(self, o2):
         return self._act(1, o2).flatten()
 
+    def choose_goal_batch(self, o2_rows):
+        """choose_goal for several observation windows at once (the eight lanes of an intersection at a
+        decision point, agent.py:405-419) -> [n, a2_dim]: one launch chain and one host round trip."""
+        return self._policy_batch(1, o2_rows)
+
     def learn(self, worker_policy=None, indices=None, noise=None, order=None):
         self._learn(indices, noise, order)
 
@@ -1000,6 +1005,11 @@ class HATD3Triple(_FlatReplayMixin, TD3Learner):
 
     def choose_goal(self, o3):
         return self._act(2, o3).flatten()
+
+    def choose_goal_batch(self, o3_rows):
+        """choose_goal for several observation windows at once (the eight lanes of an intersection at a
+        decision point, agent.py:405-419) -> [n, a3_dim]: one launch chain and one host round trip."""
+        return self._policy_batch(2, o3_rows)
 
     def learn(self, worker_policy=None, indices=None, noise=None, order=None):
         self._learn(indices, noise, order)

@@ -49,6 +49,9 @@ class OracleNet:
     def choose_goal(self, o):
         return self.td3.choose(2, o)
 
+    def choose_goal_batch(self, rows):
+        return np.stack([self.td3.choose(2, o) for o in rows])
+
     def choose_action(self, o, g):
         return self.td3.choose(0, o, g)
 
@@ -140,7 +143,7 @@ def test_four_intersections_batched_inference_same_values():
         torch.cuda.synchronize()
         outs.append((c, tr, mgr.memory.copy(), wrk.memory.copy(), mgr.state_dicts(), wrk.state_dicts(), wrk.total_it))
     (c0, t0, mm0, wm0, ms0, ws0, steps), (c1, t1, mm1, wm1, ms1, ws1, _) = outs
-    assert c1["encode"] * 16 == c0["encode"] and c1["decode"] * 4 < c0["decode"] and c1["choose_worker"] * 2 < c0["choose_worker"]
+    assert c1["encode"] * 16 == c0["encode"] and c1["decode"] * 4 < c0["decode"] and c1["choose_worker"] * 2 < c0["choose_worker"] and c1["choose_manager"] * 2 < c0["choose_manager"]
     assert c0["learn_worker"] == c1["learn_worker"] > 0 and c0["learn_manager"] == c1["learn_manager"] > 0
     for key in t0:
         scaled_close(key, np.stack(t1[key]), np.stack(t0[key]), atol_rel=2e-6 if key in ("enc", "adv") else 2e-4)

@@ -102,7 +102,8 @@ def run(encoder, manager, worker, stream: Stream, seconds: int, seed: int = 0, v
     calls (encodings, advised speeds, actions) for comparison between implementations.  `batched` uses
     the calls the reference does not have: the eight lanes of a light in one `encode_lanes` call (shared
     by manager and worker, which encode the same lanes), the advised speeds of all head CAVs of a light in
-    one `decode_host` call and their actions in one `policy` call; the values are the same."""
+    one `decode_host` call, their actions in one `policy` call and the eight lanes' goals at a decision point in
+    one `choose_goal_batch` call; the values are the same."""
     rng = np.random.RandomState(seed)
     g2 = 2 * encoder.goal_dim
     T = manager.fam.streams[0].T
@@ -168,11 +169,21 @@ def run(encoder, manager, worker, stream: Stream, seconds: int, seed: int = 0, v
                 cur_o, cur_a = [], []
                 for l in range(N_LANES):
                     lane_id = np.tile(np.eye(N_LANES)[l], (T, 1))
-                    og = np.concatenate((g_obs, e[:, l, :], lane_id), 1).flatten().tolist()
-                    cur_o.append(og)
-                    ag = rng.random_sample(a_dims[2]) * 2 - 1 if explore else timed("choose", manager.choose_goal, og)
+                    cur_o.append(np.concatenate((g_obs, e[:, l, :], lane_id), 1).flatten().tolist())
+                goals = None
+                if batched and not explore:                     # the eight lanes' goals in one call
+                    goals = np.asarray(timed("choose", manager.choose_goal_batch, np.array(cur_o)), dtype=np.float64)
+                    cnt["choose_manager"] += 1
+                for l in range(N_LANES):
+                    og = cur_o[l]
+                    if explore:
+                        ag = rng.random_sample(a_dims[2]) * 2 - 1
+                    elif goals is not None:
+                        ag = goals[l]
+                    else:
+                        ag = timed("choose", manager.choose_goal, og)
+                        cnt["choose_manager"] += 1
                     ag = np.clip(rng.normal(0, var, size=ag.shape) + ag, -1, 1)
-                    cnt["choose_manager"] += 0 if explore else 1
                     cur_a.append(ag)
                     reward = (2 * reward + lane_r[l]) / 3                       # agent.py:423 (running, as written)
                     if len(o_t[L]) >= 2 and len(o_g[L]) >= 1:
