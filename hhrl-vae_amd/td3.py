@@ -267,14 +267,19 @@ class CriticNet:
         w = self.work(B)
         ops.copy2d(src, ld_src, P(w.xu, self.act_col), self.D, B, self.fam.act_dim)
 
+    def head_descs(self, d, start: int, B: int, q1_only: bool = False) -> None:
+        """Fills d[start] (and d[start + 1]) with the forward pass of head 1 (and head 2) on w.xu."""
+        w = self.work(B)
+        self.mlp3[0].desc(d[start], P(w.xu), self.D, P(w.q1), 1, P(w.a1), P(w.a2))
+        if not q1_only:
+            self.mlp3[1].desc(d[start + 1], P(w.xu), self.D, P(w.q2), 1, P(w.b1), P(w.b2))
+
     def heads(self, B: int, q1_only: bool = False) -> None:
         w = self.work(B)
         h0, h1 = self.h
         if self.mlp3 is not None:
             d = ops.mlp3_descs(1 if q1_only else 2)
-            self.mlp3[0].desc(d[0], P(w.xu), self.D, P(w.q1), 1, P(w.a1), P(w.a2))
-            if not q1_only:
-                self.mlp3[1].desc(d[1], P(w.xu), self.D, P(w.q2), 1, P(w.b1), P(w.b2))
+            self.head_descs(d, 0, B, q1_only)
             ops.mlp3_forward_group(d, B)
             return
         if q1_only:
@@ -677,7 +682,18 @@ class TD3Learner:
         # target policies: layer k of every actor in one launch, then the smoothing noise
         for k, a in enumerate(self.actor_targets):
             a.bind_input(B, next_obs[k][0], W)
-        self._actors_forward(self.actor_targets, B, [(P(pi[k]), fam.a_dims[k]) for k in range(len(self.actors))])
+        # with fused three-layer networks throughout, the critic's own heads on the replayed (s, a) -- they depend
+        # on the minibatch only -- ride in the target policies' launch instead of taking one of their own below
+        n_a = len(self.actors)
+        heads_early = c.mlp3 is not None and all(a.mlp3 is not None for a in self.actor_targets) and n_a + 2 <= 8
+        if heads_early:
+            d = ops.mlp3_descs(n_a + 2)
+            for k, a in enumerate(self.actor_targets):
+                a.fused_desc(d[k], B, P(pi[k]), fam.a_dims[k])
+            c.head_descs(d, n_a, B)
+            ops.mlp3_forward_group(d, B)
+        else:
+            self._actors_forward(self.actor_targets, B, [(P(pi[k]), fam.a_dims[k]) for k in range(n_a)])
         for k in range(len(self.actors)):
             check(lib.hhrl_td3_smooth_action(P(pi[k]), fam.a_dims[k], P(noise[k]), P(cw_t.xu, ct.act_cols[k]), ct.D, B,
                                              fam.a_dims[k], sp))
@@ -687,7 +703,8 @@ class TD3Learner:
         # -- critic step: :1341-1350 / 799-808
         c.opt.zero_grad()
         self._loss.zero_()
-        c.heads(B)
+        if not heads_early:
+            c.heads(B)
         check(lib.hhrl_twin_mse(P(cw.q1), P(cw.q2), P(y), inv_n, P(self._loss), P(cw.d_q1), P(cw.d_q2), B, sp))
         c.backward(B, both_heads=True, param_grads=True, lstms=False)
         self._lstm_backward([c.lstm_bwd_item(k, B) for k in range(n_str)], B)
