@@ -267,6 +267,16 @@ class CriticNet:
         w = self.work(B)
         ops.copy2d(src, ld_src, P(w.xu, self.act_col), self.D, B, self.fam.act_dim)
 
+    def level_items(self, level: int, B: int):
+        """Layer `level` (1..3) of both heads on w.xu as entries of ops.linear_forward_group."""
+        w = self.work(B)
+        h0, h1 = self.h
+        if level == 1:
+            return [(self.l1, P(w.xu), self.D, P(w.a1), h0), (self.l4, P(w.xu), self.D, P(w.b1), h0)]
+        if level == 2:
+            return [(self.l2, P(w.a1), h0, P(w.a2), h1), (self.l5, P(w.b1), h0, P(w.b2), h1)]
+        return [(self.l3, P(w.a2), h1, P(w.q1), 1), (self.l6, P(w.b2), h1, P(w.q2), 1)]
+
     def head_descs(self, d, start: int, B: int, q1_only: bool = False) -> None:
         """Fills d[start] (and d[start + 1]) with the forward pass of head 1 (and head 2) on w.xu."""
         w = self.work(B)
@@ -288,9 +298,8 @@ class CriticNet:
             self.l3.fwd(P(w.a2), h1, P(w.q1), 1, B)
             return
         # the two heads are independent: layer k of both in one launch
-        ops.linear_forward_group([(self.l1, P(w.xu), self.D, P(w.a1), h0), (self.l4, P(w.xu), self.D, P(w.b1), h0)], B)
-        ops.linear_forward_group([(self.l2, P(w.a1), h0, P(w.a2), h1), (self.l5, P(w.b1), h0, P(w.b2), h1)], B)
-        ops.linear_forward_group([(self.l3, P(w.a2), h1, P(w.q1), 1), (self.l6, P(w.b2), h1, P(w.q2), 1)], B)
+        for level in (1, 2, 3):
+            ops.linear_forward_group(self.level_items(level, B), B)
 
     def lstm_backward(self, k: int, B: int) -> None:
         """BPTT of stream k's LSTM from its columns of w.d_xu (independent of the other streams)."""
@@ -692,6 +701,12 @@ class TD3Learner:
                 a.fused_desc(d[k], B, P(pi[k]), fam.a_dims[k])
             c.head_descs(d, n_a, B)
             ops.mlp3_forward_group(d, B)
+        elif c.mlp3 is None and all(a.mlp3 is None for a in self.actor_targets):
+            # layer by layer: layer k of every target actor and of both heads of the critic in one launch
+            heads_early = True
+            for level in (1, 2, 3):
+                items = [a.level_item(level, B, P(pi[k]), fam.a_dims[k]) for k, a in enumerate(self.actor_targets)]
+                ops.linear_forward_group(items + c.level_items(level, B), B)
         else:
             self._actors_forward(self.actor_targets, B, [(P(pi[k]), fam.a_dims[k]) for k in range(n_a)])
         for k in range(len(self.actors)):
