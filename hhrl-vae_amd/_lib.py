@@ -89,6 +89,7 @@ SIGNATURES = {
     "hhrl_td3_smooth_action": (_I, [_P, _I, _P, _P, _I, _I, _I, _P]),
     "hhrl_td3_target_q": (_I, [_P, _P, _P, _I, _F, _P, _I, _P]),
     "hhrl_twin_mse": (_I, [_P, _P, _P, _F, _P, _P, _P, _I, _P]),
+    "hhrl_td3_target_mse": (_I, [_P, _P, _P, _I, _F, _P, _P, _F, _P, _P, _P, _P, _I, _P]),
     "hhrl_lstm_workspace_floats": (_L, [_I, _I, _I, _I]),
     "hhrl_lstm_forward": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "hhrl_lstm_backward": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),

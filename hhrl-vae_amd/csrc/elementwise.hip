@@ -93,6 +93,43 @@ __global__ __launch_bounds__(256) void twin_mse_kernel(const float* __restrict__
   }
 }
 
+// Target value and twin critic loss in one pass: y = r + gamma min(q1t, q2t), then the two mean squared errors
+// and their gradients as in twin_mse_kernel.  ONE: a single workgroup walks all rows and stores the two losses;
+// otherwise the workgroups add their shares to a loss that was zeroed before the launch.
+template <bool ONE>
+__global__ __launch_bounds__(256) void td3_target_mse_kernel(const float* __restrict__ q1t, const float* __restrict__ q2t,
+                                                             const float* __restrict__ r, int ldr, float gamma,
+                                                             const float* __restrict__ q1, const float* __restrict__ q2,
+                                                             float inv_n, float* y, float* loss, float* dq1, float* dq2, int B) {
+  __shared__ float red[2][4];
+  const int stride = gridDim.x * blockDim.x;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += stride) {
+    const float yi = r[(long)i * ldr] + gamma * fminf(q1t[i], q2t[i]);
+    y[i] = yi;
+    const float d1 = q1[i] - yi, d2 = q2[i] - yi;
+    s1 += d1 * d1;
+    s2 += d2 * d2;
+    dq1[i] = 2.f * inv_n * d1;
+    dq2[i] = 2.f * inv_n * d2;
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float l1 = inv_n * (red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    const float l2 = inv_n * (red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    if (ONE) {
+      loss[0] = l1;
+      loss[1] = l2;
+    } else {
+      unsafeAtomicAdd(&loss[0], l1);
+      unsafeAtomicAdd(&loss[1], l2);
+    }
+  }
+}
+
 // ---------------------------------------------------------- optimiser
 // One coalesced pass: reads p,g,m,v (16 B each), writes p,m,v: 28 B / parameter.
 // copy_dst (optional): one float copied from copy_src by the first thread, for a value that travels behind
@@ -308,6 +345,23 @@ int hhrl_twin_mse(const float* q1, const float* q2, const float* y, float inv_n,
   ProfScope ps("twin_mse_kernel", as_stream(stream), 0.0, 20.0 * B);
   hipLaunchKernelGGL(twin_mse_kernel, dim3(stream_grid(B)), dim3(256), 0, as_stream(stream), q1, q2, y, inv_n, loss, dq1, dq2, B);
   return launch_status("twin_mse_kernel");
+}
+
+int hhrl_td3_target_mse(const float* q1t, const float* q2t, const float* r, int ldr, float gamma, const float* q1,
+                        const float* q2, float inv_n, float* y, float* loss, float* dq1, float* dq2, int B, void* stream) {
+  HHRL_REQUIRE(q1t && q2t && r && q1 && q2 && y && loss && dq1 && dq2, "td3_target_mse: null pointer");
+  HHRL_REQUIRE(B > 0 && ldr >= 1, "td3_target_mse: B=%d ldr=%d", B, ldr);
+  hipStream_t st = as_stream(stream);
+  ProfScope ps("td3_target_mse_kernel", st, 0.0, 32.0 * B);
+  if (B <= 8192) {
+    hipLaunchKernelGGL(td3_target_mse_kernel<true>, dim3(1), dim3(256), 0, st, q1t, q2t, r, ldr, gamma, q1, q2, inv_n, y, loss,
+                       dq1, dq2, B);
+  } else {
+    if (hipMemsetAsync(loss, 0, 2 * sizeof(float), st) != hipSuccess) return fail(HHRL_ERR_HIP, "td3_target_mse: memset failed");
+    hipLaunchKernelGGL(td3_target_mse_kernel<false>, dim3(stream_grid(B)), dim3(256), 0, st, q1t, q2t, r, ldr, gamma, q1, q2,
+                       inv_n, y, loss, dq1, dq2, B);
+  }
+  return launch_status("td3_target_mse_kernel");
 }
 
 static int adam_launch(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2, double eps,

@@ -713,14 +713,13 @@ class TD3Learner:
             check(lib.hhrl_td3_smooth_action(P(pi[k]), fam.a_dims[k], P(noise[k]), P(cw_t.xu, ct.act_cols[k]), ct.D, B,
                                              fam.a_dims[k], sp))
         ct.heads(B)
-        check(lib.hhrl_td3_target_q(P(cw_t.q1), P(cw_t.q2), R(self.col_reward), W, fam.gamma, P(y), B, sp))
 
-        # -- critic step: :1341-1350 / 799-808
+        # -- critic step: :1341-1350 / 799-808; target value, both losses and their gradients in one launch
         c.opt.zero_grad()
-        self._loss.zero_()
         if not heads_early:
             c.heads(B)
-        check(lib.hhrl_twin_mse(P(cw.q1), P(cw.q2), P(y), inv_n, P(self._loss), P(cw.d_q1), P(cw.d_q2), B, sp))
+        check(lib.hhrl_td3_target_mse(P(cw_t.q1), P(cw_t.q2), R(self.col_reward), W, fam.gamma, P(cw.q1), P(cw.q2), inv_n,
+                                      P(y), P(self._loss), P(cw.d_q1), P(cw.d_q2), B, sp))
         c.backward(B, both_heads=True, param_grads=True, lstms=False)
         self._lstm_backward([c.lstm_bwd_item(k, B) for k in range(n_str)], B)
         self._allreduce(c.opt.g)

@@ -190,6 +190,12 @@ int hhrl_td3_target_q(const float* q1, const float* q2, const float* r, int ldr,
  *   dq1 = 2*inv_n*(q1-y); dq2 = 2*inv_n*(q2-y).   loss[2] zeroed by the caller. */
 int hhrl_twin_mse(const float* q1, const float* q2, const float* y, float inv_n, float* loss,
                   float* dq1, float* dq2, int B, void* stream);
+/* hhrl_td3_target_q followed by hhrl_twin_mse in one launch (same lines of algorithm.py): y is computed from the
+ * target critic's q1t, q2t and the reward column and stored, then the two losses and their gradients follow.
+ * loss[0..1] are OVERWRITTEN (no zeroing by the caller). */
+int hhrl_td3_target_mse(const float* q1t, const float* q2t, const float* r, int ldr, float gamma,
+                        const float* q1, const float* q2, float inv_n, float* y, float* loss,
+                        float* dq1, float* dq2, int B, void* stream);
 
 /* ------------------------------------------------- three dense layers, fused
  * y = act3(W3 relu(W2 relu(W1 x + b1) + b2) + b3) as one launch per direction for a GROUP of

@@ -275,6 +275,37 @@ def test_td3_elementwise(env):
     scaled_close("mse", loss.cpu().numpy(), [float(l1), float(l2)])
     scaled_close("dq1", dq1.cpu().numpy(), q1.grad.numpy())
     scaled_close("dq2", dq2.cpu().numpy(), q2.grad.numpy())
+    # the same two steps as one launch: y stored, the losses overwritten (no zeroing by the caller)
+    y2 = torch.zeros(B, 1, device=dev)
+    loss2 = torch.full((2,), 7.0, device=dev)
+    e1, e2 = torch.zeros(B, 1, device=dev), torch.zeros(B, 1, device=dev)
+    L.check(lib.hhrl_td3_target_mse(tq1d.data_ptr(), tq2d.data_ptr(), rd.data_ptr(), 1, 0.95, q1d.data_ptr(), q2d.data_ptr(),
+                                    1.0 / B, y2.data_ptr(), loss2.data_ptr(), e1.data_ptr(), e2.data_ptr(), B, st))
+    assert torch.equal(y2, yd) and torch.equal(e1, dq1) and torch.equal(e2, dq2)
+    scaled_close("mse fused", loss2.cpu().numpy(), [float(l1), float(l2)])
+
+
+@pytest.mark.parametrize("B", [1, 256, 8192, 9001])
+def test_td3_target_mse_equals_two_launches(env, B):
+    """hhrl_td3_target_mse against hhrl_td3_target_q + hhrl_twin_mse: one workgroup up to 8192 rows, several with
+    a zeroed loss and atomics beyond; strided reward column as in a replay row."""
+    lib, L, dev = env
+    g = torch.Generator().manual_seed(B)
+    st = L.stream_ptr()
+    q1, q2, t1, t2 = (torch.randn(B, 1, generator=g).to(dev) for _ in range(4))
+    rows = torch.randn(B, 5, generator=g).to(dev)
+    r_ptr = rows.data_ptr() + 4 * 3
+    y_a, y_b = torch.zeros(B, 1, device=dev), torch.zeros(B, 1, device=dev)
+    la, lb = torch.zeros(2, device=dev), torch.full((2,), -3.0, device=dev)
+    d1a, d2a, d1b, d2b = (torch.zeros(B, 1, device=dev) for _ in range(4))
+    L.check(lib.hhrl_td3_target_q(t1.data_ptr(), t2.data_ptr(), r_ptr, 5, 0.9, y_a.data_ptr(), B, st))
+    L.check(lib.hhrl_twin_mse(q1.data_ptr(), q2.data_ptr(), y_a.data_ptr(), 1.0 / B, la.data_ptr(), d1a.data_ptr(), d2a.data_ptr(), B, st))
+    L.check(lib.hhrl_td3_target_mse(t1.data_ptr(), t2.data_ptr(), r_ptr, 5, 0.9, q1.data_ptr(), q2.data_ptr(), 1.0 / B,
+                                    y_b.data_ptr(), lb.data_ptr(), d1b.data_ptr(), d2b.data_ptr(), B, st))
+    assert torch.equal(y_a, y_b) and torch.equal(d1a, d1b) and torch.equal(d2a, d2b)
+    want = rows[:, 3:4] + 0.9 * torch.minimum(t1, t2)
+    scaled_close("y", y_b.cpu().numpy(), want.cpu().numpy(), rtol=1e-6)
+    scaled_close("loss", lb.cpu().numpy(), la.cpu().numpy(), rtol=1e-5)
 
 
 @pytest.mark.parametrize("B,T,o,H", [(9, 5, 7, 12), (64, 10, 13, 128), (64, 10, 25, 128), (3, 1, 4, 8), (130, 4, 5, 8)])
