@@ -43,7 +43,8 @@ class Mlp3Desc(C.Structure):
                 ("N3", _I), ("act3", _I), ("h1", _P), ("h2", _P), ("y", _P), ("ldy", _I),
                 ("dy", _P), ("lddy", _I), ("dy_const", _F),
                 ("gw1", _P), ("gb1", _P), ("gw2", _P), ("gb2", _P), ("gw3", _P), ("gb3", _P),
-                ("dx", _P), ("lddx", _I)]
+                ("dx", _P), ("lddx", _I),
+                ("smooth_eps", _P), ("y2", _P), ("ldy2", _I)]
 
 
 MLP3_GROUP_MAX = 8
@@ -138,11 +139,34 @@ def check(rc: int) -> None:
         raise HipError("libhhrl_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
 
 
+_raw_stream = None
+_streams = {}
+
+
 def stream_ptr() -> int:
     """The raw hipStream_t of torch's current stream: kernels are enqueued
-    there so they order with torch's own copies and allocations."""
+    there so they order with torch's own copies and allocations.  Read through torch's C accessor:
+    `torch.cuda.current_stream()` builds a Stream object and resolves the device each time, ten
+    microseconds that every entry-point call and every update would pay."""
+    global _raw_stream
     import torch
+    if _raw_stream is None:
+        _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", False)
+    if _raw_stream:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+def current_stream():
+    """torch's current stream as a `torch.cuda.Stream`, cached per (device, raw handle)."""
+    import torch
+    key = (torch.cuda.current_device(), stream_ptr())
+    st = _streams.get(key)
+    if st is None:
+        if len(_streams) > 64:
+            _streams.clear()
+        st = _streams[key] = torch.cuda.current_stream()
+    return st
 
 
 def prof_report() -> dict:

@@ -27,8 +27,10 @@ struct Net {
   float *h1, *h2, *y;
   const float* dy;
   float *gw1, *gb1, *gw2, *gb2, *gw3, *gb3, *dx;
+  const float* smooth_eps;
+  float* y2;
   float dy_const;
-  int ldx, ldy, lddy, lddx, K0, N3, act3;
+  int ldx, ldy, lddy, lddx, K0, N3, act3, ldy2;
 };
 struct NetGroup { Net in[kMaxNets]; };
 
@@ -181,7 +183,15 @@ __global__ __launch_bounds__(NT, 1) void mlp3_forward_kernel(NetGroup grp, int M
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int row = row0 + 16 * rb + 4 * q + e;
-      if (row < M && col < g.N3) g.y[(long)row * g.ldy + col] = act_apply(c[e], g.act3);
+      if (row < M && col < g.N3) {
+        const float v = act_apply(c[e], g.act3);
+        g.y[(long)row * g.ldy + col] = v;
+        if (g.smooth_eps != nullptr) {      // target-policy smoothing of the same value, as td3_smooth_action_kernel
+          float n = 0.2f * g.smooth_eps[(long)row * g.N3 + col];
+          n = fminf(fmaxf(n, -0.5f), 0.5f);
+          g.y2[(long)row * g.ldy2 + col] = fminf(fmaxf(v + n, -1.f), 1.f);
+        }
+      }
     }
   }
   if (g.h1 != nullptr) {
@@ -369,6 +379,7 @@ static int fill_group(NetGroup& grp, const hhrl_mlp3_desc* d, int n, int M, bool
     HHRL_REQUIRE(!s.h1 || (aligned16(s.h1) && aligned16(s.h2)), "mlp3: network %d: h1/h2 must be 16-byte aligned", i);
     if (!backward) {
       HHRL_REQUIRE(s.y && s.ldy >= s.N3, "mlp3_forward: network %d: y missing or ldy=%d < N3", i, s.ldy);
+      HHRL_REQUIRE(!s.smooth_eps || (s.y2 && s.ldy2 >= s.N3), "mlp3_forward: network %d: smoothing needs y2 with ldy2 >= N3", i);
     } else {
       HHRL_REQUIRE(s.h1, "mlp3_backward: network %d: needs the hidden activations saved by the forward call", i);
       HHRL_REQUIRE(!s.dy || s.lddy >= s.N3, "mlp3_backward: network %d: lddy=%d < N3", i, s.lddy);
@@ -384,6 +395,7 @@ static int fill_group(NetGroup& grp, const hhrl_mlp3_desc* d, int n, int M, bool
     g.h1 = s.h1; g.h2 = s.h2; g.y = s.y; g.dy = s.dy;
     g.gw1 = s.gw1; g.gb1 = s.gb1; g.gw2 = s.gw2; g.gb2 = s.gb2; g.gw3 = s.gw3; g.gb3 = s.gb3; g.dx = s.dx;
     g.dy_const = s.dy_const;
+    g.smooth_eps = backward ? nullptr : s.smooth_eps; g.y2 = s.y2; g.ldy2 = s.ldy2;
     g.ldx = s.ldx; g.ldy = s.ldy; g.lddy = s.lddy; g.lddx = s.lddx; g.K0 = s.K0; g.N3 = s.N3; g.act3 = s.act3;
   }
   return HHRL_OK;

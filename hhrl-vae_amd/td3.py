@@ -574,7 +574,7 @@ class TD3Learner:
         else:
             st.d_in.copy_(st.h_in[slot], non_blocking=True)
         ev = torch.cuda.Event()
-        ev.record()
+        ev.record(_lib.current_stream())
         st.events[slot] = ev
         st.gather = gather                                  # the update starts by gathering its rows on the device
         key = (B, policy, order, gather)
@@ -695,12 +695,16 @@ class TD3Learner:
         # on the minibatch only -- ride in the target policies' launch instead of taking one of their own below
         n_a = len(self.actors)
         heads_early = c.mlp3 is not None and all(a.mlp3 is not None for a in self.actor_targets) and n_a + 2 <= 8
+        smoothed = False
         if heads_early:
             d = ops.mlp3_descs(n_a + 2)
             for k, a in enumerate(self.actor_targets):
                 a.fused_desc(d[k], B, P(pi[k]), fam.a_dims[k])
+                # the smoothing noise is applied in the launch's epilogue, straight into the target critic's input
+                d[k].smooth_eps, d[k].y2, d[k].ldy2 = P(noise[k]), P(cw_t.xu, ct.act_cols[k]), ct.D
             c.head_descs(d, n_a, B)
             ops.mlp3_forward_group(d, B)
+            smoothed = True
         elif c.mlp3 is None and all(a.mlp3 is None for a in self.actor_targets):
             # layer by layer: layer k of every target actor and of both heads of the critic in one launch
             heads_early = True
@@ -709,7 +713,7 @@ class TD3Learner:
                 ops.linear_forward_group(items + c.level_items(level, B), B)
         else:
             self._actors_forward(self.actor_targets, B, [(P(pi[k]), fam.a_dims[k]) for k in range(n_a)])
-        for k in range(len(self.actors)):
+        for k in range(len(self.actors) if not smoothed else 0):
             check(lib.hhrl_td3_smooth_action(P(pi[k]), fam.a_dims[k], P(noise[k]), P(cw_t.xu, ct.act_cols[k]), ct.D, B,
                                              fam.a_dims[k], sp))
         ct.heads(B)
@@ -844,7 +848,7 @@ class TD3Learner:
             io["calls"] += 1
             run()
         h_out.copy_(d_out, non_blocking=True)
-        torch.cuda.current_stream().synchronize()        # the pinned blocks are free again afterwards
+        _lib.current_stream().synchronize()        # the pinned blocks are free again afterwards
         return h_out.numpy().copy()
 
     # ---- checkpoints ------------------------------------------------------

@@ -101,7 +101,7 @@ class _InferIO:
 
     def download(self, n: int) -> np.ndarray:
         self.h_out[:n].copy_(self.d_out[:n], non_blocking=True)
-        torch.cuda.current_stream().synchronize()
+        _lib.current_stream().synchronize()
         return self.h_out_np[:n].copy()
 
 

@@ -217,6 +217,9 @@ typedef struct {
   const float* dy; int lddy; float dy_const;
   float *gw1, *gb1, *gw2, *gb2, *gw3, *gb3;
   float* dx; int lddx;
+  /* forward only, optional: the target-policy smoothing of hhrl_td3_smooth_action applied to the output in the
+   * same launch: y2[row*ldy2 + col] = clamp(y + clamp(0.2*smooth_eps[row*N3 + col], -0.5, 0.5), -1, 1) */
+  const float* smooth_eps; float* y2; int ldy2;
 } hhrl_mlp3_desc;
 int hhrl_mlp3_supported(int K0, int H1, int H2, int N3);
 int hhrl_mlp3_forward_group(const hhrl_mlp3_desc* nets, int n, int M, void* stream);

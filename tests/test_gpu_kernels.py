@@ -489,8 +489,15 @@ def test_mlp3_fused_matches_torch(env, M, K0, N3, act3):
         keep.append((xd, dyd, wd, gd, h1, h2, yd, dxd))
         refs.append((y.detach(), xt.grad, [w.grad for w in wt]))
     st = L.stream_ptr()
+    # network 0 also hands its output through the target-policy smoothing, into a wider row
+    sm_eps = (torch.randn(M, N3, generator=g) * 3).to(dev)
+    sm_out = torch.full((M, N3 + 3), 5.0, device=dev)
+    descs[0].smooth_eps, descs[0].y2, descs[0].ldy2 = sm_eps.data_ptr(), sm_out.data_ptr() + 4 * 2, N3 + 3
     L.check(lib.hhrl_mlp3_forward_group(descs, n, M, st))
     L.check(lib.hhrl_mlp3_backward_group(descs, n, M, st))
+    sm_want = torch.full((M, N3 + 3), 5.0, device=dev)
+    L.check(lib.hhrl_td3_smooth_action(keep[0][6].data_ptr(), ldy, sm_eps.data_ptr(), sm_want.data_ptr() + 4 * 2, N3 + 3, M, N3, st))
+    assert torch.equal(sm_out, sm_want)
     for i in range(n):
         y, dx, gws = refs[i]
         xd, dyd, wd, gd, h1, h2, yd, dxd = keep[i]
