@@ -119,9 +119,13 @@ class FlatAdam:
 
 
 class StepLR:
-    """lr = base_lr * gamma ** (calls // step_size)  — torch's StepLR with the
-    reference's gamma = 0.5 (algorithm.py:260-261).  Computed on the host; the
-    value reaches the Adam kernel as a scalar argument."""
+    """torch's StepLR with the reference's gamma = 0.5 (algorithm.py:260-261) in its chainable form:
+    every `step_size`-th call multiplies the optimizer's CURRENT lr by gamma.  For a fresh optimizer that
+    is base_lr * gamma ** (calls // step_size) bit for bit (halving is exact); after
+    `FlatAdam.load_state_dict` it keeps the decayed lr the checkpoint carries and goes on halving it from
+    there, as torch does when the reference resumes (algorithm.py:1375-1382: load() restores the optimizer's
+    param_groups, the scheduler object keeps counting its own calls).  Computed on the host; the value
+    reaches the Adam kernel as a scalar argument."""
 
     def __init__(self, opt: FlatAdam, step_size: int, gamma: float = 0.5):
         self.opt = opt
@@ -131,4 +135,5 @@ class StepLR:
 
     def step(self) -> None:
         self.epoch += 1
-        self.opt.lr = self.opt.base_lr * self.gamma ** (self.epoch // self.step_size)
+        if self.epoch % self.step_size == 0:
+            self.opt.lr *= self.gamma

@@ -172,6 +172,32 @@ class Encoder:
         self._io = _InferIO(self.device)
         self._host_rng = np.random.default_rng(3407 if seed is None else seed)      # decode()'s noise (algorithm.py:125)
 
+    # ------------------------------------------------------------ nn.Module manners the callers use
+    def to(self, device=None, *args, **kwargs) -> "Encoder":
+        """`Encoder(2, goal_dim).to(device)` (VAE_train.py:64; the reference's Encoder is an nn.Module).
+        Parameters live on the GPU chosen at construction: a matching (or unspecified) CUDA device is
+        accepted and `self` returned; anything else raises, there is no CPU path."""
+        if device is not None and not isinstance(device, (torch.dtype,)):
+            d = torch.device(device)
+            if d.type != "cuda" or (d.index is not None and self.device.index is not None and d.index != self.device.index):
+                raise RuntimeError("Encoder lives on %s and cannot move to %s (no CPU path; construct it with device=...)"
+                                   % (self.device, d))
+        return self
+
+    def cuda(self, device=None) -> "Encoder":
+        return self.to("cuda" if device is None else device)
+
+    def train(self, mode: bool = True) -> "Encoder":
+        """No dropout or batch statistics anywhere in the model: training and evaluation modes coincide."""
+        return self
+
+    def eval(self) -> "Encoder":
+        return self
+
+    def parameters(self):
+        """Views of the flat parameter buffer in `nn.Module.parameters()` order (algorithm.py:83)."""
+        return [self.params[n] for n in self.layout.names]
+
     # ------------------------------------------------------------ helpers
     def _ws(self, B: int, N: int) -> _Work:
         w = self._work.get((B, N))

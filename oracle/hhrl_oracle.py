@@ -147,15 +147,17 @@ class Adam:
 
 
 class StepLR:
-    """torch.optim.lr_scheduler.StepLR(step_size, gamma): lr is multiplied by
-    gamma every ``step_size`` calls of ``step()``."""
+    """torch.optim.lr_scheduler.StepLR(step_size, gamma), chainable form: the optimizer's current lr is
+    multiplied by gamma on every ``step_size``-th call of ``step()`` (so an lr restored from a checkpoint
+    keeps decaying from where it was, algorithm.py:1375-1382)."""
 
     def __init__(self, opt: Adam, step_size: int, gamma: float = 0.5):
         self.opt, self.step_size, self.gamma, self.epoch = opt, int(step_size), gamma, 0
 
     def step(self) -> None:
         self.epoch += 1
-        self.opt.lr = self.opt.base_lr * self.gamma ** (self.epoch // self.step_size)
+        if self.epoch % self.step_size == 0:
+            self.opt.lr *= self.gamma
 
 
 class VAE:

@@ -97,7 +97,59 @@ def worker():
     print("wrote WorkerTD3 checkpoint fixture")
 
 
+def worker_decayed():
+    """As worker(), with scheduler steps of 1 (actor) and 2 (critic): the saved optimizers carry an lr that
+    StepLR has already halved, and the updates after the resume cross further decay boundaries
+    (algorithm.py:1283-1294, 1375-1382)."""
+    case = "ckpt_worker_decayed"
+    cfg = gen.cav_cfg(o=5, g=3, hidden=(16, 12), batch=8, cap=48, a_sched=1, c_sched=2)
+    net = build_ref("worker", None, cfg)
+    for a in ("actor", "critic"):
+        mod = getattr(net, a)
+        shp = [(k, tuple(v.shape)) for k, v in mod.state_dict().items()]
+        st = gen.gen_state(shp, gen.case_seed(case, "init_" + a))
+        load_np(mod, st)
+        load_np(getattr(net, a + "_target"), st)
+    rows = gen.gen_rows(40, net.memory.shape[1], gen.case_seed(case, "rows"))
+    net.memory[:40] = rows
+    net.pointer = 40
+    for call in range(4):
+        np.random.seed(gen.case_seed(case, "call%d" % call))
+        torch.manual_seed(gen.case_seed(case, "call%d" % call))
+        net.learn()
+    prefix = os.path.join(OUT, "ref_worker_decayed")
+    net.save(prefix)
+    out = {"meta": META, "rows": rows}
+    out["saved/critic_lr"] = np.float64(net.critic_optimizer.param_groups[0]["lr"])
+    out["saved/actor_lr"] = np.float64(net.actor_optimizer.param_groups[0]["lr"])
+    n2 = build_ref("worker", None, cfg)
+    n2.load(prefix)
+    n2.memory[:40] = rows
+    n2.pointer = 40
+    n_next = 4
+    lrs = np.zeros((n_next, 2))
+    for call in range(n_next):
+        seed = gen.case_seed(case, "next%d" % call)
+        np.random.seed(seed)
+        out["next%d/indices" % call] = np.random.choice(40, size=cfg["batch_size"])
+        torch.manual_seed(seed)
+        out["next%d/eps" % call] = torch.randn(cfg["batch_size"], 1).numpy().copy()
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        n2.learn()
+        lrs[call] = (n2.critic_optimizer.param_groups[0]["lr"], n2.actor_optimizer.param_groups[0]["lr"])
+    out["next/lrs"] = lrs                                   # (critic, actor) lr after each resumed update
+    put(out, "next/param/critic", sd_np(n2.critic.state_dict()))
+    put(out, "next/param/actor", sd_np(n2.actor.state_dict()))
+    put(out, "next/target/critic", sd_np(n2.critic_target.state_dict()))
+    np.savez_compressed(os.path.join(OUT, "ref_worker_decayed_expect.npz"), **out)
+    print("wrote WorkerTD3 decayed-lr checkpoint fixture: saved lrs %g %g, after resume %s"
+          % (out["saved/critic_lr"], out["saved/actor_lr"], lrs.tolist()))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    vae()
-    worker()
+    if "--decayed-only" not in sys.argv:
+        vae()
+        worker()
+    worker_decayed()

@@ -120,6 +120,57 @@ def test_vae_train_all_converts_chunks_once(tmp_path):
             assert os.path.exists(os.path.join(str(tmp_path), "encoder_dim_%d%s" % (g, suf)))
 
 
+def test_reference_training_script_body_runs_unchanged(tmp_path):
+    """The train-mode body of the reference's script (VAE_train.py:52-69) with only its import swapped to
+    `hhrl_vae_amd.algorithm.Encoder`: state log read from disk in the script's own format, chunks of 64,
+    shuffle, `Encoder(2, goal_dim).to(device)`, one `learn` per chunk with the loss handed to a tensorboard-like
+    writer, `save`.  The statements below are the script's call sequence; the writer and the paths are local."""
+    import json
+    import os
+    import random
+    from hhrl_vae_amd.algorithm import Encoder
+    from hhrl_vae_amd.vae_train import read_state_log, train_one_pass
+    rs = np.random.RandomState(3407)
+    log = {str(n): rs.uniform(0, 1, size=(cnt, n, 2)).tolist() for n, cnt in ((0, 0), (1, 70), (4, 130), (9, 64), (23, 17))}
+    log_path = os.path.join(str(tmp_path), "0814_sample_2.txt")
+    with open(log_path, "w") as f:
+        json.dump(log, f)
+
+    class Writer:
+        def __init__(self):
+            self.scalars = []
+
+        def add_scalar(self, tag, value, step):
+            self.scalars.append((tag, float(value), step))
+    writer = Writer()
+    device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    my_dataset = read_state_log(log_path)
+    batch_size = 64
+    dataset = {k: [v[i: i + batch_size] for i in range(0, len(v), batch_size)] for k, v in my_dataset.items() if len(v) > 0}
+    shuffled_dataset = [item for sublist in dataset.values() for item in sublist]
+    random.Random(3407).shuffle(shuffled_dataset)
+    for goal_dim in [2, 4, 8, 16]:
+        cnt, loss = 0, 0
+        encoder = Encoder(2, goal_dim).to(device)
+        for data in shuffled_dataset:
+            loss = encoder.learn(data)
+            writer.add_scalar(str(goal_dim) + '_loss', loss, cnt)
+            cnt += 1
+        encoder.save(os.path.join(str(tmp_path), 'encoder_dim_' + str(goal_dim)))
+    n_chunks = 2 + 3 + 1 + 1
+    assert len(shuffled_dataset) == n_chunks and len(writer.scalars) == 4 * n_chunks
+    for goal_dim in [2, 4, 8, 16]:
+        got = [v for tag, v, _ in writer.scalars if tag == str(goal_dim) + '_loss']
+        assert all(np.isfinite(got)) and isinstance(got[0], float)
+        assert got == train_one_pass(Encoder(2, goal_dim), shuffled_dataset)      # same seeds, same steps: same bits
+        for suf in ("_enc", "_dec", "_encoder_optimizer"):
+            assert os.path.exists(os.path.join(str(tmp_path), "encoder_dim_%d%s" % (goal_dim, suf)))
+    e = Encoder(2, 4)
+    assert e.to("cuda") is e and e.eval() is e and e.train() is e and len(e.parameters()) == 24
+    with pytest.raises(RuntimeError):
+        e.to("cpu")
+
+
 def adam_conditioned_close(name, got_p, want_p, want_g, lr, g_floor, rtol=1e-4):
     """Parameters after an Adam step.  Adam normalises the gradient, so an
     early step moves a weight by about lr * g/|g|: a gradient element known

@@ -73,6 +73,47 @@ def test_steplr_rule_matches_torch():
         assert fo.lr == pytest.approx(topt.param_groups[0]["lr"], rel=1e-15)
 
 
+def test_steplr_keeps_a_restored_lr_like_torch():
+    """After an optimizer state with an already-decayed lr is loaded, torch's StepLR goes on halving THAT lr
+    (algorithm.py:1375-1382 restores param_groups; the scheduler object only counts calls).  Checked against
+    torch itself and against the lr sequence the reference produced after its own load()
+    (tests/golden/ckpt/ref_worker_decayed_expect.npz, written by make_ckpt.py)."""
+    import os
+    from hhrl_vae_amd.optim import StepLR
+
+    class FakeOpt:
+        lr = base_lr = 1e-3
+    p = torch.nn.Parameter(torch.zeros(1))
+    src = torch.optim.Adam([p], lr=1e-3)
+    ssch = torch.optim.lr_scheduler.StepLR(src, step_size=2, gamma=0.5)
+    for _ in range(5):
+        src.step()
+        ssch.step()
+    saved = src.state_dict()
+    assert saved["param_groups"][0]["lr"] == 2.5e-4
+    topt = torch.optim.Adam([p], lr=1e-3)
+    tsch = torch.optim.lr_scheduler.StepLR(topt, step_size=2, gamma=0.5)
+    topt.load_state_dict(saved)
+    fo = FakeOpt()
+    sch = StepLR(fo, 2)
+    fo.lr, fo.base_lr = saved["param_groups"][0]["lr"], saved["param_groups"][0]["initial_lr"]   # FlatAdam.load_state_dict
+    for _ in range(7):
+        topt.step()
+        tsch.step()
+        sch.step()
+        assert fo.lr == topt.param_groups[0]["lr"]
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ckpt", "ref_worker_decayed_expect.npz"))
+    crit, act = FakeOpt(), FakeOpt()
+    crit.lr, act.lr = float(fx["saved/critic_lr"]), float(fx["saved/actor_lr"])
+    assert crit.lr == 2.5e-4 and act.lr == 2.5e-5                    # the checkpoint carries decayed rates
+    cs, as_ = StepLR(crit, 2), StepLR(act, 1)
+    for call, (want_c, want_a) in enumerate(fx["next/lrs"]):
+        cs.step()
+        if (call + 1) % 2 == 0:                                      # actor scheduler: policy steps only (algorithm.py:1353-1366)
+            as_.step()
+        assert (crit.lr, act.lr) == (want_c, want_a), call
+
+
 def test_vae_chunking_matches_golden_loop():
     from hhrl_vae_amd.vae_train import chunk_dataset, shuffle_chunks
     fx = load_case("vae_loop_g2")
