@@ -9,12 +9,22 @@ backward, Adam) per GPU.  N=1 workload: 4096 lanes x 7 cars, latent 4, fp32,
 synthetic lanes already in HBM.  N>1: every rank holds its own 4096-lane
 shard (weak scaling, global batch N*4096), gradients are all-reduced (RCCL)
 once per step.  Rank 0 prints ONE JSON line.
+
+Started without a launcher (`python bench.py --gpus N`, no WORLD_SIZE in the
+environment) the script starts its N ranks itself, as fresh child processes
+of `python -m torch.distributed.run`, before anything in this process has
+touched a GPU, and passes rank 0's JSON line on.  On a box with fewer than N
+GPUs it prints a line that says so (value null) and exits 0; with
+`--rehearse` it runs the N ranks on the one GPU over the gloo backend
+instead -- every code path of the N-rank run, no scaling number.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,9 +34,11 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from hhrl_vae_amd import work                      # noqa: E402  (shape arithmetic only; loads no GPU code)
+
 # Chip peaks used for roofline fractions (MI355X, gfx950)
-PEAK_FP32_MATRIX_TFLOPS = 157.3     # dense f32 MFMA
-PEAK_HBM_GBS = 8000.0               # HBM3E
+PEAK_FP32_MATRIX_TFLOPS = work.PEAK_FP32_MATRIX_TFLOPS     # dense f32 MFMA
+PEAK_HBM_GBS = work.PEAK_HBM_GBS                           # HBM3E
 
 
 def vae_flops_per_lane(N: int, g: int) -> float:
@@ -88,61 +100,140 @@ def cpu_baseline_vae(B: int, N: int, g: int, budget_s: float = 12.0) -> dict:
             "ms_per_step": 1e3 * dt / steps}
 
 
-def agent_update_rates(device, steps: int) -> dict:
-    """Extra fields: TD3 update minibatches/s from synthetic replay
-    (WorkerTD3 row width 36 and HATD3Triple row width 1030, batch 64)."""
+AGENT_CASES = (("worker_td3_b64", "worker", 64, 4096), ("worker_td3_b4096", "worker", 4096, 8192),
+               ("hatd3_triple_b64", "triple", 64, 2048), ("hatd3_triple_b1024", "triple", 1024, 2048))
+
+
+def _agent_net(kind: str, batch: int, cap: int, device, group=None):
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import gen
     from hhrl_vae_amd.algorithm import HATD3Triple, WorkerTD3
+    if kind == "worker":
+        return WorkerTD3(gen.cav_cfg(cap=cap, batch=batch), device=str(device), group=group, seed=3407)
+    return HATD3Triple(gen.light_cfg(cap=cap, batch=batch), device=str(device), group=group, seed=3407)
+
+
+def cpu_baseline_td3(kind: str, batch: int, budget_s: float = 4.0) -> dict:
+    """The CPU oracle's TD3 update (PyTorch fp32 restatement of the reference's learn()) timed on this box's
+    host cores on the same minibatch shape, replay gather included, for about `budget_s` seconds."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import gen
+    import hhrl_oracle as O
+    cfg = gen.cav_cfg(batch=batch) if kind == "worker" else gen.light_cfg(batch=batch)
+    fam = O.family_from_cfg(kind, cfg)
+    t = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}
+    actors = [t(gen.gen_state(O.actor_param_shapes(fam, k), 21 + k)) for k in range(len(fam.a_dims))]
+    net = O.TD3(fam, actors, t(gen.gen_state(O.critic_param_shapes(fam), 20)))
+    rows = np.random.RandomState(3407).uniform(0, 1, size=(2048, fam.row_width))
+    rs = np.random.RandomState(1)
+    gen_t = torch.Generator().manual_seed(1)
+
+    def one():
+        idx = rs.randint(0, rows.shape[0], size=batch)
+        noise = [torch.randn(batch, a, generator=gen_t) for a in fam.a_dims]
+        net.learn(O.split_rows(fam, rows[idx]), noise, list(rs.permutation(len(fam.a_dims))))
+    for _ in range(2):
+        one()
+    t0, n = time.perf_counter(), 0
+    while True:
+        one()
+        n += 1
+        if n >= 2 and n % 2 == 0 and time.perf_counter() - t0 > budget_s:       # whole policy cycles
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "minibatches/s", "cores": torch.get_num_threads(), "kind": "port",
+            "ms_per_update": 1e3 * dt / n,
+            "sample": "%d updates of the CPU oracle's TD3 learn at batch %d (%s), %.1f s" % (n, batch, kind, dt)}
+
+
+def agent_update_rates(device, steps: int, group=None, world: int = 1, cpu_baseline: bool = True) -> dict:
+    """Extra fields: TD3 update minibatches/s from synthetic replay (WorkerTD3 row width 36 and HATD3Triple
+    row width 1030), each with its place on the roofline (algorithmic FLOPs and bytes from the layer shapes,
+    hhrl_vae_amd/work.py) and, on one GPU, the CPU oracle's rate on the same shape.  With a process group the
+    batch named is PER RANK (weak scaling): a global minibatch of world x batch rows, one gradient all-reduce
+    per optimizer step; time = max over ranks."""
+    import torch.distributed as dist
     out = {}
-    for name, net, n_rows in (("worker_td3_b64", WorkerTD3(gen.cav_cfg(cap=4096), device=str(device)), 4096),
-                              ("worker_td3_b4096", WorkerTD3(gen.cav_cfg(cap=8192, batch=4096), device=str(device)), 8192),
-                              ("hatd3_triple_b64", HATD3Triple(gen.light_cfg(cap=2048), device=str(device)), 2048),
-                              ("hatd3_triple_b1024", HATD3Triple(gen.light_cfg(cap=2048, batch=1024), device=str(device)), 2048)):
-        rows = np.random.RandomState(3407).uniform(0, 1, size=(n_rows, net.fam.row_width))
+    for name, kind, batch, n_rows in AGENT_CASES:
+        net = _agent_net(kind, batch, n_rows, device, group)
+        rank = dist.get_rank(group) if group is not None else 0
+        rows = np.random.RandomState(3407 + rank).uniform(0, 1, size=(n_rows, net.fam.row_width))
         net.memory[:n_rows] = rows
         net.pointer = n_rows
         n_orders = 1
         for k in range(2, len(net.actors) + 1):
             n_orders *= k
         # warm up until every (policy step, actor order) launch chain has its final form (graph or eager);
-        # a chain needs six runs, a given actor order comes up once in 2 * n_orders updates
+        # a chain needs up to six runs, a given actor order comes up once in 2 * n_orders updates.  Data-parallel
+        # ranks run the same number of updates (the actor order is rank 0's draw, so their chains agree).
         for it in range(60 * n_orders):
             net.learn()
             forms = net.launch_forms()
-            if it >= 30 and len(forms) == 1 + n_orders and "tuning" not in forms.values():
+            done = it >= 30 and len(forms) == 1 + n_orders and "tuning" not in forms.values()
+            if group is not None:
+                flag = torch.tensor([1.0 if done else 0.0], device=device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                done = bool(flag.item() > 0.5)
+            if done:
                 break
         # ... and until the device has been busy with this update for half a second: the update chains that
         # are bound by the GPU (device-resident replay) are measured at the clocks the chip settles on
         torch.cuda.synchronize()
         t_w, n_w = time.perf_counter(), 0
-        while time.perf_counter() - t_w < 0.5:
+        n_warm = None
+        if group is not None:
+            n_warm = 200 if batch <= 64 else 50                                   # same count on every rank
+        while (time.perf_counter() - t_w < 0.5) if n_warm is None else (n_w < n_warm):
             net.learn()
             n_w += 1
         torch.cuda.synchronize()
         n_timed = max(steps, int(0.25 * n_w / (time.perf_counter() - t_w)))          # at least a quarter of a second
+        if group is not None:
+            cnt = torch.tensor([float(n_timed)], device=device)
+            dist.all_reduce(cnt, op=dist.ReduceOp.MAX, group=group)
+            n_timed = int(cnt.item())
+            dist.barrier(group=group)
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n_timed):
             net.learn()
+        if group is not None:
+            dist.barrier(group=group)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        if group is not None:
+            tt = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=group)
+            dt = float(tt.item())
+        w = work.td3_update(net.fam, batch)
         out[name] = {"minibatches_per_s": n_timed / dt, "ms_per_update": 1e3 * dt / n_timed,
-                     "rows_per_s": n_timed * net.batch_size / dt, "updates_timed": n_timed}
-        # one policy evaluation as the agents call it every control step (host round trip included)
-        fam = net.fam
-        o = rows[0, :fam.streams[0].width]
-        if fam.goal_dim:
-            act = lambda: net.choose_action(o, rows[1, :fam.goal_dim])
-        elif hasattr(net, "choose_time_action"):
-            act = lambda: net.choose_time_action(o)
-        else:
-            act = lambda: net.choose_action(o)
-        for _ in range(10):
-            act()
-        t0 = time.perf_counter()
-        for _ in range(100):
-            act()
-        out[name]["choose_action_us"] = 1e4 * (time.perf_counter() - t0)
+                     "rows_per_s": world * n_timed * net.batch_size / dt, "updates_timed": n_timed,
+                     "rows_per_rank": batch, "global_rows": world * batch,
+                     # per GPU: every rank does this work on its shard
+                     "roofline": dict(work.roofline(w["flops"], w["bytes"], dt / n_timed),
+                                      flops_per_update=w["flops"], bytes_per_update=w["bytes"], macs_per_row=w["macs_per_row"]),
+                     "launch_forms": sorted(set(net.launch_forms().values()))}
+        if group is None:
+            # one policy evaluation as the agents call it every control step (host round trip included)
+            fam = net.fam
+            o = rows[0, :fam.streams[0].width]
+            if fam.goal_dim:
+                act = lambda: net.choose_action(o, rows[1, :fam.goal_dim])
+            elif hasattr(net, "choose_time_action"):
+                act = lambda: net.choose_time_action(o)
+            else:
+                act = lambda: net.choose_action(o)
+            for _ in range(10):
+                act()
+            t0 = time.perf_counter()
+            for _ in range(100):
+                act()
+            out[name]["choose_action_us"] = 1e4 * (time.perf_counter() - t0)
+        del net
+    if cpu_baseline and group is None:
+        for name, kind, batch, _ in AGENT_CASES:
+            out[name]["cpu_baseline"] = cpu_baseline_td3(kind, batch, 4.0 if batch <= 64 else 6.0)
     return out
 
 
@@ -195,6 +286,44 @@ def pmc_traffic(workload: str, kernel: str, suffix: str = "_hbm_traffic.json", f
     return best
 
 
+def _free_port() -> int:
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def launch_ranks(args, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children of
+    `python -m torch.distributed.run` (this process never touches a GPU: counting devices does not
+    initialise one) and pass rank 0's JSON line on."""
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and not args.rehearse:
+        msg = ("bench.py --gpus %d needs %d GPUs on this node, %d visible (add --rehearse to run the %d ranks on one "
+               "GPU over gloo: all code paths, no scaling number)" % (args.gpus, args.gpus, n_dev, args.gpus))
+        print(msg, file=sys.stderr)
+        print(json.dumps({"metric": "VAE train lane-samples/s", "value": None, "unit": "lane-samples/s", "n_gpus": args.gpus,
+                          "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "error": msg}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.rehearse:
+        env["HHRL_BENCH_REHEARSE"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    return proc.returncode if line is not None or proc.returncode != 0 else 1
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -203,16 +332,24 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=4096, help="lanes per GPU")
     ap.add_argument("--cars", type=int, default=7)
     ap.add_argument("--latent", type=int, default=4)
+    ap.add_argument("--windows", type=int, default=9, help="further timed windows of --steps steps each (spread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-agents", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N ranks on ONE GPU over gloo (exercises the N-rank path; not a scaling number)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, world, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    rehearse = os.environ.get("HHRL_BENCH_REHEARSE") == "1" or (args.rehearse and world > 1)
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     group = None
@@ -223,7 +360,10 @@ def main() -> None:
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
         group = dist.group.WORLD
 
     from hhrl_vae_amd import _lib
@@ -240,20 +380,27 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_window(k: int) -> float:
+        """K steps between barriers; max over ranks."""
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            enc.learn(x, sync=False, global_count=gcount)
+        barrier()
+        d = time.perf_counter() - t0
+        if group is not None:
+            import torch.distributed as dist
+            t = torch.tensor([d], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d = float(t.item())
+        return d
+
     for _ in range(args.warmup):
         enc.learn(x, sync=False, global_count=gcount)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        enc.learn(x, sync=False, global_count=gcount)
-    barrier()
-    dt = time.perf_counter() - t0
-    if group is not None:
-        import torch.distributed as dist
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = timed_window(args.steps)                       # THE timed region: exactly --steps steps
     value = world * B * args.steps / dt
+    # the same window repeated: how much one short window says
+    more = sorted(timed_window(args.steps) for _ in range(max(args.windows, 0)))
 
     # the same region with the batch handed over from pinned host memory each step (reported beside `value`)
     x_host = x.cpu().pin_memory()
@@ -279,6 +426,12 @@ def main() -> None:
     lib.hhrl_prof_enable(0)
     prof = _lib.prof_report()
     lib.hhrl_prof_reset()
+
+    agents = None
+    if not args.no_agents:
+        # every rank takes part in the data-parallel updates; only rank 0 reports
+        agents = agent_update_rates(device, max(20, min(args.steps, 100)), group if world > 1 else None, world,
+                                    cpu_baseline=not args.no_cpu_baseline)
 
     if rank == 0:
         kernels = {k: dict(v, ms_per_step=v["ms"] / prof_steps) for k, v in prof.items()}
@@ -323,6 +476,10 @@ def main() -> None:
             "config": {"workload": workload, "lanes_per_gpu": B, "cars_per_lane": N,
                        "latent": g, "global_batch": B * world, "parallelism": "dp%d" % world},
             "roofline": roof,
+            "windows": {"n": len(more), "steps_each": args.steps,
+                        "ms_per_step_min": 1e3 * more[0] / args.steps if more else None,
+                        "ms_per_step_median": 1e3 * more[len(more) // 2] / args.steps if more else None,
+                        "ms_per_step_max": 1e3 * more[-1] / args.steps if more else None},
             "value_with_h2d_per_step": world * B * args.steps / dt_h2d,
             "step_algorithmic_tflops": step_alg_tflops,
             "step_frac_of_fp32_matrix_peak": step_alg_tflops / PEAK_FP32_MATRIX_TFLOPS,
@@ -332,8 +489,11 @@ def main() -> None:
             "kernels": {k: {"launches_per_step": v["launches"] / prof_steps, "ms_per_step": v["ms_per_step"]}
                         for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])},
         }
+        if rehearse:
+            out["rehearsal"] = "%d ranks on one GPU over gloo: exercises the N-rank path, not a scaling number" % world
+        if agents is not None:
+            out["agent_updates"] = agents
         if world == 1 and not args.no_agents:
-            out["agent_updates"] = agent_update_rates(device, max(20, min(args.steps, 100)))
             out["inference"] = inference_latency(enc, device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_vae(B, N, g)

@@ -416,28 +416,35 @@ class TD3Learner:
         self.memory_capacity = fam.memory_capacity
         self.learn_begin = fam.memory_capacity * fam.learn_start_ratio
         self.group = group
-        self.world_size = 1
+        self.world_size, self.rank = 1, 0
         if group is not None:
             import torch.distributed as dist
-            self.world_size = dist.get_world_size(group)
-        self._np_rng = np.random.default_rng(3407 if seed is None else seed)     # smoothing noise (algorithm.py:295, 1330)
+            self.world_size, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        # smoothing noise (algorithm.py:295, 1330).  Data-parallel ranks share `seed` (identical initial weights)
+        # but hold different shards of the global minibatch: each rank's noise stream is offset by its rank, so
+        # that the global batch carries independent draws like the single-device update of the same rows would
+        self._np_rng = np.random.default_rng((3407 if seed is None else seed) + 1000003 * self.rank)
         self._loss = ops.dev_zeros(2, device=dev)
         self._statics: Dict[int, "TD3Learner._Static"] = {}
         self._policy_io: Dict[Tuple[int, int], dict] = {}
         self._graphs: Dict[tuple, "torch.cuda.CUDAGraph"] = {}
+        # data-parallel: a launch chain is captured as one graph per stretch between two all-reduces
+        self._seg_graphs: Dict[tuple, list] = {}
+        self._sync_hook = None
         self._seen: Dict[tuple, int] = {}
         if use_graph not in (True, False, "auto"):
             raise ValueError("use_graph must be True, False or 'auto'")
         self.use_graph = use_graph
         # device_replay: the flat replay buffer is mirrored in device memory (new rows are uploaded before an
         # update) and a minibatch is gathered there from the sampled row numbers, instead of being gathered
-        # on the host and uploaded whole.  Classes with a flat `memory` array only, single device only.
+        # on the host and uploaded whole.  Classes with a flat `memory` array only.  Data-parallel ranks each
+        # mirror their own replay buffer (a rank samples its shard of the global minibatch from its own rows).
         # "auto" (default): on when a minibatch is at least AUTO_DEVICE_REPLAY_FLOATS wide x long, where gathering
         # it on the host and uploading it costs more than the extra gather launch (HATD3Triple at batch 64:
         # 0.715 -> 0.682 ms; WorkerTD3 at batch 4096: 0.181 -> 0.136 ms; WorkerTD3 at batch 64: 0.090 -> 0.099 ms)
         if device_replay == "auto":
             device_replay = fam.batch_size * fam.row_width >= self.AUTO_DEVICE_REPLAY_FLOATS
-        self.device_replay = bool(device_replay) and group is None
+        self.device_replay = bool(device_replay)
         self._tune: Dict[tuple, dict] = {}
         # column offsets inside a replay row
         f = fam
@@ -509,14 +516,17 @@ class TD3Learner:
             return slot
 
     def learn_rows(self, rows, noise: Optional[Sequence] = None, order: Optional[Sequence[int]] = None,
-                   _indices=None) -> None:
+                   _indices=None, global_batch: Optional[int] = None) -> None:
         """One TD3 update on a [B, row_width] block of replay rows (numpy array, host or device tensor).
         _indices (device replay, rows=None): the B row numbers to gather from the device mirror instead.
 
         The kernel sequence of an update depends only on (B, policy step?, actor order); after two
         eager runs of a given combination it is captured into a HIP graph and replayed.  What changes
         from update to update (rows, noise, the scalars of the Adam steps) reaches the device in one
-        transfer before the replay."""
+        transfer before the replay.
+
+        global_batch (data-parallel): rows of the global minibatch over all ranks, the divisor of the batch
+        means (default: this rank's rows x world size, i.e. equal shards)."""
         fam = self.fam
         W = fam.row_width
         gather = _indices is not None
@@ -577,7 +587,10 @@ class TD3Learner:
         ev.record(_lib.current_stream())
         st.events[slot] = ev
         st.gather = gather                                  # the update starts by gathering its rows on the device
-        key = (B, policy, order, gather)
+        st.global_batch = int(global_batch) if global_batch is not None else B * self.world_size
+        if st.global_batch < B:
+            raise ValueError("global_batch %d is smaller than this rank's %d rows" % (st.global_batch, B))
+        key = (B, policy, order, gather, st.global_batch)
         self._run_body(key, st, B, policy, order)
         # host-side bookkeeping of what was just enqueued
         self.critic.opt.commit_step()
@@ -594,15 +607,17 @@ class TD3Learner:
         so far; a benchmark warms up until none is "tuning" and every chain it expects has come up."""
         out = {}
         for key in self._seen:
-            if key in self._graphs:
+            if key in self._graphs or key in self._seg_graphs:
                 form = "graph"
-            elif self.use_graph is False or self.group is not None:
+            elif self.use_graph is False:
                 form = "eager"
+            elif self.group is not None:
+                form = "tuning"                 # captured after two eager runs
             elif self.use_graph is True:
                 form = "tuning"
             else:
                 form = "eager" if self._tune.get(key, {}).get("done") else "tuning"
-            if form == "graph" and self.use_graph == "auto" and not self._tune[key]["done"]:
+            if form == "graph" and self.group is None and self.use_graph == "auto" and not self._tune[key]["done"]:
                 form = "tuning"
             out[key] = form
         return out
@@ -616,8 +631,10 @@ class TD3Learner:
         the form with the shorter enqueue-to-finished time of ONE update is kept.  Back-to-back updates
         favour the graph more than that single-update latency shows (HATD3Triple: 0.68 ms replayed against
         0.76 ms eager in a loop, equal within noise when timed one at a time), hence the default."""
+        if self.group is not None:
+            return self._run_body_group(key, st, B, policy, order)
         graph = self._graphs.get(key)
-        mode = self.use_graph if self.group is None else False
+        mode = self.use_graph
         tune = self._tune.get(key) if mode == "auto" else None
         if mode == "auto" and tune is None:
             tune = self._tune[key] = {"eager": [], "graph": [], "done": False}
@@ -651,6 +668,62 @@ class TD3Learner:
                 if min(tune["graph"]) > min(tune["eager"]):
                     del self._graphs[key]                     # eager is faster for this launch chain
 
+    def _run_body_group(self, key, st, B: int, policy: bool, order: Sequence[int]) -> None:
+        """Data-parallel form of _run_body.  An update has one gradient all-reduce per optimizer step
+        (critic, then every actor of a policy step); the kernels between two all-reduces are captured as a
+        HIP graph of their own after two eager runs of the launch chain, and an update is then
+        graph, all-reduce, graph, ... (2 to 5 replays and 1 to 4 collectives instead of up to ~120 launches).
+        The collectives stay outside the graphs: they belong to the process group's own stream handling."""
+        from . import dist as hdist
+        segs = self._seg_graphs.get(key)
+        if segs is None:
+            if not self.use_graph or self._seen.get(key, 0) < 2:
+                self._seen[key] = self._seen.get(key, 0) + 1
+                self._update_body(st, B, policy, order)
+                return
+            segs = self._capture_segments(st, B, policy, order)
+            self._seg_graphs[key] = segs
+        for graph, flat in segs:
+            graph.replay()
+            if flat is not None:
+                hdist.allreduce_sum_(flat, self.group)
+
+    def _capture_segments(self, st, B: int, policy: bool, order: Sequence[int]) -> list:
+        """Runs _update_body under stream capture, cutting the capture at every all-reduce point:
+        [(graph, flat gradient to all-reduce after it, or None for the last stretch)].  Nothing executes."""
+        segs: list = []
+        stream = torch.cuda.Stream(device=self.device)
+        pool = torch.cuda.graph_pool_handle()
+        cur = {}
+
+        def begin():
+            cur["graph"] = torch.cuda.CUDAGraph()
+            # thread-local capture mode: the process group's helper threads may still be finishing HIP calls of
+            # the previous collective (event queries, pinned-buffer bookkeeping), which the default global mode
+            # would count as violations of this thread's capture
+            cur["ctx"] = torch.cuda.graph(cur["graph"], pool=pool, stream=stream, capture_error_mode="thread_local")
+            cur["ctx"].__enter__()
+
+        def cut(flat):
+            cur["ctx"].__exit__(None, None, None)
+            segs.append((cur["graph"], flat))
+            if flat is not None:
+                begin()
+
+        torch.cuda.synchronize()
+        self._sync_hook = cut
+        try:
+            begin()
+            try:
+                self._update_body(st, B, policy, order)
+            except BaseException:
+                cur["ctx"].__exit__(None, None, None)      # never leave the stream capturing
+                raise
+            cut(None)
+        finally:
+            self._sync_hook = None
+        return segs
+
     def _update_body(self, st: "TD3Learner._Static", B: int, policy: bool, order: Sequence[int]) -> None:
         """The kernel sequence of one update (no host-side state changes)."""
         fam, lib, sp = self.fam, self._lib, _lib.stream_ptr()
@@ -658,7 +731,7 @@ class TD3Learner:
         rows, noise, pi, y = st.rows, st.noise, st.pi, st.y
         if getattr(st, "gather", False):
             check(lib.hhrl_gather_rows(P(self._dev_mem), W, self.memory_capacity, st.idx.data_ptr(), P(rows), W, B, W, sp))
-        inv_n = 1.0 / float(B * self.world_size)
+        inv_n = 1.0 / float(getattr(st, "global_batch", B * self.world_size))
         R = lambda col: P(rows, col)
         goal = R(self.col_goal) if fam.goal_dim else None
         next_goal = R(self.col_next_goal) if fam.goal_dim else None
@@ -788,17 +861,20 @@ class TD3Learner:
 
     def _allreduce(self, g: FlatBuffer) -> None:
         if self.group is not None:
+            if self._sync_hook is not None:         # under capture: the collective runs between the graphs
+                self._sync_hook(g.data)
+                return
             from . import dist as hdist
             hdist.allreduce_sum_(g.data, self.group)
 
-    def _learn(self, indices=None, noise=None, order=None) -> None:
+    def _learn(self, indices=None, noise=None, order=None, global_batch=None) -> None:
         if indices is None:
             indices = np.random.choice(min(self._n_stored(), self.memory_capacity), size=self.batch_size)
         if self.device_replay and hasattr(self, "_sync_replay"):
             self._sync_replay()
-            self.learn_rows(None, noise, order, _indices=np.asarray(indices))
+            self.learn_rows(None, noise, order, _indices=np.asarray(indices), global_batch=global_batch)
         else:
-            self.learn_rows(self._sample_rows(np.asarray(indices)), noise, order)
+            self.learn_rows(self._sample_rows(np.asarray(indices)), noise, order, global_batch=global_batch)
 
     # ---- inference --------------------------------------------------------
     def _act(self, k: int, obs, goal=None) -> np.ndarray:
@@ -965,8 +1041,8 @@ class TD3Single(_FlatReplayMixin, TD3Learner):
     def choose_action(self, o):
         return self._act(0, o).flatten()
 
-    def learn(self, indices=None, noise=None, order=None):
-        self._learn(indices, noise, order)
+    def learn(self, indices=None, noise=None, order=None, global_batch=None):
+        self._learn(indices, noise, order, global_batch)
 
 
 class HATD3Double(_FlatReplayMixin, TD3Learner):
@@ -999,8 +1075,8 @@ class HATD3Double(_FlatReplayMixin, TD3Learner):
         decision point, agent.py:405-419) -> [n, a2_dim]: one launch chain and one host round trip."""
         return self._policy_batch(1, o2_rows)
 
-    def learn(self, worker_policy=None, indices=None, noise=None, order=None):
-        self._learn(indices, noise, order)
+    def learn(self, worker_policy=None, indices=None, noise=None, order=None, global_batch=None):
+        self._learn(indices, noise, order, global_batch)
 
 
 class HATD3(HATD3Double):
@@ -1046,8 +1122,8 @@ class HATD3Triple(_FlatReplayMixin, TD3Learner):
         decision point, agent.py:405-419) -> [n, a3_dim]: one launch chain and one host round trip."""
         return self._policy_batch(2, o3_rows)
 
-    def learn(self, worker_policy=None, indices=None, noise=None, order=None):
-        self._learn(indices, noise, order)
+    def learn(self, worker_policy=None, indices=None, noise=None, order=None, global_batch=None):
+        self._learn(indices, noise, order, global_batch)
 
 
 class ManagerTD3(TD3Learner):
@@ -1127,10 +1203,10 @@ class ManagerTD3(TD3Learner):
     def choose_action(self, o_l):
         return self._act(0, o_l).flatten()
 
-    def learn(self, worker_policy=None, indices=None, noise=None, order=None):
+    def learn(self, worker_policy=None, indices=None, noise=None, order=None, global_batch=None):
         self._worker_policy = worker_policy
         try:
-            self._learn(indices, noise, order)
+            self._learn(indices, noise, order, global_batch)
         finally:
             self._worker_policy = None
 
@@ -1156,5 +1232,5 @@ class WorkerTD3(_FlatReplayMixin, TD3Learner):
         """Batched policy for the manager's off-policy correction (algorithm.py:1310-1314)."""
         return self._policy_batch(0, o, g)
 
-    def learn(self, indices=None, noise=None, order=None):
-        self._learn(indices, noise, order)
+    def learn(self, indices=None, noise=None, order=None, global_batch=None):
+        self._learn(indices, noise, order, global_batch)

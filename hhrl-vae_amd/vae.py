@@ -122,7 +122,7 @@ class Encoder:
     EPS_POOL = 1 << 20
 
     def __init__(self, car_info_dim: int, goal_dim: int, device: Optional[str] = None, seed: Optional[int] = None,
-                 group=None, fused: bool = True):
+                 group=None, fused: bool = True, static_shards: bool = False):
         if car_info_dim != 2:
             raise ValueError("the lane state is (location, speed): car_info_dim must be 2 (algorithm.py:94-95)")
         if not torch.cuda.is_available():
@@ -160,17 +160,25 @@ class Encoder:
         self._loss_scalars = [self._loss_ring[i] for i in range(self.LOSS_RING)]
         self._loss_ptrs = [v.data_ptr() for v in self._loss_views]
         self._loss = self._loss_views[0]
-        self._rng = torch.Generator(device=self.device)
-        self._rng.manual_seed(3407)
-        self._eps_pool = None           # reparameterisation noise is drawn EPS_POOL floats at a time
-        self._eps_used = 0
         self.group = group
-        self.world_size = 1
+        self.world_size, self.rank = 1, 0
         if group is not None:
             import torch.distributed as dist
-            self.world_size = dist.get_world_size(group)
+            self.world_size, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        # Noise generators (reparameterisation, algorithm.py:89, 125).  Data-parallel ranks share `seed` (identical
+        # initial weights) but hold different lanes: their noise streams are offset by the rank, so the global
+        # batch carries independent draws.
+        noise_seed = (3407 if seed is None else seed) + 1000003 * self.rank
+        self._rng = torch.Generator(device=self.device)
+        self._rng.manual_seed(noise_seed)
+        self._eps_pool = None           # reparameterisation noise is drawn EPS_POOL floats at a time
+        self._eps_used = 0
+        # static_shards: every rank hands the same shard shape to every learn() call, so the global element
+        # count is all-reduced once per shard shape and reused (no host round trip per step)
+        self.static_shards = bool(static_shards)
+        self._global_counts: Dict[int, int] = {}
         self._io = _InferIO(self.device)
-        self._host_rng = np.random.default_rng(3407 if seed is None else seed)      # decode()'s noise (algorithm.py:125)
+        self._host_rng = np.random.default_rng(noise_seed)      # decode()'s noise (algorithm.py:125)
 
     # ------------------------------------------------------------ nn.Module manners the callers use
     def to(self, device=None, *args, **kwargs) -> "Encoder":
@@ -357,7 +365,8 @@ class Encoder:
 
         Data-parallel (group set): `data` is this rank's shard; the squared
         error is divided by the GLOBAL element count (`global_count`, or an
-        all-reduced count when omitted), KL stays a sum, and the flat gradient
+        all-reduced count when omitted: a host round trip per step unless the
+        encoder was built with static_shards=True), KL stays a sum, and the flat gradient
         buffer is all-reduced (SUM) once before the Adam step, so every rank
         applies the single-device update for the global batch."""
         if self.group is None:
@@ -368,7 +377,12 @@ class Encoder:
             from . import dist as hdist
             x = self._to_device(data)
             if global_count is None:
-                global_count = hdist.global_count(int(x.shape[0] * x.shape[1]), self.group, self.device)
+                local = int(x.shape[0] * x.shape[1])
+                global_count = self._global_counts.get(local) if self.static_shards else None
+                if global_count is None:
+                    global_count = hdist.global_count(local, self.group, self.device)     # one small all-reduce + host read
+                    if self.static_shards:
+                        self._global_counts[local] = global_count
             g = self.opt.g
             if self.fused:
                 loss = self.loss_and_grads(x, eps, recon_count=global_count, _loss_to_tail=True)

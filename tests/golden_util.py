@@ -62,3 +62,28 @@ def td3_inputs(case: str, fx: Dict[str, np.ndarray], shapes_by_net):
         rows = gen.gen_rows(n_rows, width, gen.case_seed(case, "rows"))
         init = {net: gen.gen_state(shp, gen.case_seed(case, "init_" + net)) for net, shp in shapes_by_net.items()}
     return init, rows
+
+
+def adam_path_close(name, got_p, want_p, grads_by_step, lrs, g_floor=2e-6, rtol=1e-4):
+    """Parameters after a sequence of Adam steps, element by element.
+
+    Adam normalises the gradient: a step moves a weight by about lr * g/|g| while the moments are young, so a
+    gradient element that two fp32 evaluations know only to within dg (their summation noise, taken as
+    g_floor * max|g| of the tensor at that step) makes that step uncertain by about lr * dg/|g|, and by a full
+    step (at most ~2.2 lr, the largest bias-corrected ratio) where the sign itself is undetermined.  The bar is
+    the rtol of the specification plus a scale floor plus the SUM of those per-step terms: it stays tight for
+    every element whose gradient is well above the noise and does not grow with the number of steps for them.
+
+    grads_by_step: list of {tensor name: reference gradient at that step}; lrs: the lr of each step."""
+    acc = {k: 0.0 for k in want_p}
+    for grads, lr in zip(grads_by_step, lrs):
+        for k in want_p:
+            g = np.abs(np.asarray(grads[k], dtype=np.float64))
+            dg = g_floor * max(float(g.max()) if g.size else 0.0, 1e-30)
+            acc[k] = acc[k] + lr * np.minimum(2.2, 6.0 * dg / (g + 1e-30))
+    for k, w in want_p.items():
+        wp, gp = np.asarray(w, dtype=np.float64), np.asarray(got_p[k], dtype=np.float64)
+        tol = rtol * np.abs(wp) + 2e-6 * float(np.abs(wp).max() if wp.size else 0.0) + acc[k]
+        err = np.abs(gp - wp)
+        assert np.all(err <= tol), "%s/%s: %d of %d elements out, worst excess %.3e (bar there %.3e)" % (
+            name, k, int((err > tol).sum()), err.size, float((err - tol).max()), float(tol.reshape(-1)[np.argmax(err - tol)]))
