@@ -33,6 +33,11 @@ inline int launch_status(const char* what) {
     if (_rc != HHRL_OK) return _rc; \
   } while (0)
 
+// Kernels that use more than 64 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised.
+// The attribute belongs to the CURRENT DEVICE's instance of the function, so it is set once per
+// (device, kernel) here, under a lock (first calls may come from several threads or for several devices).
+int ensure_dyn_lds(const void* fn, int bytes, const char* who);
+
 constexpr int kWave = 64;  // CDNA wavefront width
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -1,6 +1,10 @@
 // Dense layer forward/backward and the strided data-movement kernels.
 #include "common.h"
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 namespace hhrl {
 
 static thread_local char g_err[512];
@@ -11,6 +15,20 @@ int fail(int code, const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return code;
+}
+
+int ensure_dyn_lds(const void* fn, int bytes, const char* who) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, int> done;     // (device, kernel) -> bytes granted
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return fail(HHRL_ERR_HIP, "%s: hipGetDevice failed", who);
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = done.find({dev, fn});
+  if (it != done.end() && it->second >= bytes) return HHRL_OK;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+    return fail(HHRL_ERR_HIP, "%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize, %d) failed on device %d", who, bytes, dev);
+  done[{dev, fn}] = bytes;
+  return HHRL_OK;
 }
 
 // dy <- dy * act'(y) in place, and db[col] += sum over rows.  A workgroup

@@ -384,18 +384,10 @@ __global__ __launch_bounds__(256) void colsum2_kernel(ColsumGroup grp, int ld, i
 }
 
 static int set_step_attrs(int H) {
-  static int done_for = -1;
-  if (done_for >= H) return HHRL_OK;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_forward_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)step_fwd_lds_bytes(H)) != hipSuccess ||
-      hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_forward_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)step_fwd_lds_bytes(H)) != hipSuccess ||
-      hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_backward_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)step_bwd_lds_bytes(H)) != hipSuccess ||
-      hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_backward_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)step_bwd_lds_bytes(H)) != hipSuccess)
-    return fail(HHRL_ERR_HIP, "lstm: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-  done_for = H;
+  HHRL_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(lstm_step_forward_kernel<256>), (int)step_fwd_lds_bytes(H), "lstm"));
+  HHRL_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(lstm_step_forward_kernel<512>), (int)step_fwd_lds_bytes(H), "lstm"));
+  HHRL_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(lstm_step_backward_kernel<256>), (int)step_bwd_lds_bytes(H), "lstm"));
+  HHRL_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(lstm_step_backward_kernel<512>), (int)step_bwd_lds_bytes(H), "lstm"));
   return HHRL_OK;
 }
 

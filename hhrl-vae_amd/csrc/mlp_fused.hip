@@ -352,14 +352,13 @@ __global__ __launch_bounds__(NT, 1) void mlp3_backward_kernel(NetGroup grp, int 
 // Threads per workgroup: 512 (four helper waves) unless HHRL_MLP_THREADS=256 asks for the plain form.
 static int g_threads = 0;
 static int set_attrs() {
-  if (g_threads != 0) return HHRL_OK;
   const void* fns[] = {reinterpret_cast<const void*>(mlp3_forward_kernel<256>), reinterpret_cast<const void*>(mlp3_forward_kernel<512>),
                        reinterpret_cast<const void*>(mlp3_backward_kernel<256>), reinterpret_cast<const void*>(mlp3_backward_kernel<512>)};
-  for (int i = 0; i < 4; ++i)
-    if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, L_END * 4) != hipSuccess)
-      return fail(HHRL_ERR_HIP, "mlp3: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-  const char* e = getenv("HHRL_MLP_THREADS");
-  g_threads = (e && atoi(e) == 256) ? 256 : 512;
+  for (int i = 0; i < 4; ++i) HHRL_TRY(ensure_dyn_lds(fns[i], L_END * 4, "mlp3"));
+  if (g_threads == 0) {
+    const char* e = getenv("HHRL_MLP_THREADS");
+    g_threads = (e && atoi(e) == 256) ? 256 : 512;
+  }
   return HHRL_OK;
 }
 

@@ -1708,18 +1708,16 @@ static int vae_step_impl(float* params, float* grads, float* m, float* v, const 
   if (lane_threads == 0) {
     const char* e = getenv("HHRL_LANE_THREADS");
     lane_threads = (e && atoi(e) == 256) ? 256 : 512;
+  }
+  {
     const void* fns[] = {reinterpret_cast<const void*>(vae_car_fwd_bwd_kernel),
                          reinterpret_cast<const void*>(vae_lane_forward_kernel<256>),
                          reinterpret_cast<const void*>(vae_lane_forward_kernel<512>),
                          reinterpret_cast<const void*>(vae_lane_backward_kernel<true, 256>),
                          reinterpret_cast<const void*>(vae_lane_backward_kernel<true, 512>),
                          reinterpret_cast<const void*>(vae_lane_backward_kernel<false, 256>)};
-    for (int i = 0; i < 6; ++i) {
-      if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (i == 0 ? CAR_LDS_FLOATS : LN_LDS_FLOATS) * 4) != hipSuccess) {
-        lane_threads = 0;
-        return fail(HHRL_ERR_HIP, "vae_train_step: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-      }
-    }
+    for (int i = 0; i < 6; ++i)
+      HHRL_TRY(ensure_dyn_lds(fns[i], (i == 0 ? CAR_LDS_FLOATS : LN_LDS_FLOATS) * 4, "vae_train_step"));
   }
 
   LaneArgs la;
@@ -1858,13 +1856,7 @@ int hhrl_vae_encode(const float* params, const long* offsets, long n_flat, const
   a.lane_start = lane_start;
   a.out = out;
   a.ldo = ldo;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(vae_encode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            LN_LDS_FLOATS * 4) != hipSuccess)
-      return fail(HHRL_ERR_HIP, "vae_encode: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-    attr_done = true;
-  }
+  HHRL_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(vae_encode_kernel), LN_LDS_FLOATS * 4, "vae_encode"));
   hipStream_t st = as_stream(stream);
   ProfScope ps("vae_encode_kernel", st, 0.0, 0.0);
   hipLaunchKernelGGL(vae_encode_kernel, dim3(grid_lane(B)), dim3(256), LN_LDS_FLOATS * 4, st, a);
@@ -1886,13 +1878,7 @@ int hhrl_vae_decode(const float* params, const long* offsets, long n_flat, const
   a.goal = goal; a.eps = eps; a.loc = loc; a.out = out;
   a.rows = (long)B * N;
   a.ldg = ldg; a.ldl = ldl; a.ldo = ldo; a.N = N; a.g = g;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(vae_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            DEC_LDS_FLOATS * 4) != hipSuccess)
-      return fail(HHRL_ERR_HIP, "vae_decode: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-    attr_done = true;
-  }
+  HHRL_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(vae_decode_kernel), DEC_LDS_FLOATS * 4, "vae_decode"));
   const long tiles = (a.rows + 31) / 32;
   hipStream_t st = as_stream(stream);
   ProfScope ps("vae_decode_kernel", st, 0.0, 0.0);

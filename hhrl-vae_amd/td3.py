@@ -39,6 +39,11 @@ def _lstm_default_init(layout: Layout, gen: torch.Generator) -> Dict[str, torch.
     return out
 
 
+import os as _os
+
+_DP_DEBUG = _os.environ.get("HHRL_DP_DEBUG") == "1"       # diagnostic: synchronise and report after every stretch
+
+
 # ------------------------------------------------------------------ networks
 class _ActorWork:
     def __init__(self, net: "ActorNet", B: int, dev):
@@ -417,9 +422,11 @@ class TD3Learner:
         self.learn_begin = fam.memory_capacity * fam.learn_start_ratio
         self.group = group
         self.world_size, self.rank = 1, 0
+        self._group_backend = None
         if group is not None:
             import torch.distributed as dist
             self.world_size, self.rank = dist.get_world_size(group), dist.get_rank(group)
+            self._group_backend = str(dist.get_backend(group))
         # smoothing noise (algorithm.py:295, 1330).  Data-parallel ranks share `seed` (identical initial weights)
         # but hold different shards of the global minibatch: each rank's noise stream is offset by its rank, so
         # that the global batch carries independent draws like the single-device update of the same rows would
@@ -683,10 +690,25 @@ class TD3Learner:
                 return
             segs = self._capture_segments(st, B, policy, order)
             self._seg_graphs[key] = segs
-        for graph, flat in segs:
+        dbg = _DP_DEBUG
+        # The gloo backend (CPU rehearsals and tests of the N-rank path; RCCL is the production backend) stages
+        # device tensors through the host on streams of its own and waits for the launch stream anyway.  Handing
+        # it a stream with a freshly launched graph still in flight was seen to stall that hand-over when several
+        # processes share one GPU, so the launch stream is drained first; for RCCL the collective simply queues
+        # behind the graph on the same stream.
+        drain = self._group_backend == "gloo"
+        for n, (graph, flat) in enumerate(segs):
             graph.replay()
+            if dbg:
+                torch.cuda.synchronize()
+                print("[dp rank %d] it %d key %s segment %d/%d replayed" % (self.rank, self.total_it, key[1:3], n, len(segs)), flush=True)
             if flat is not None:
+                if drain:
+                    _lib.current_stream().synchronize()
                 hdist.allreduce_sum_(flat, self.group)
+                if dbg:
+                    torch.cuda.synchronize()
+                    print("[dp rank %d] it %d segment %d all-reduced %d floats" % (self.rank, self.total_it, n, flat.numel()), flush=True)
 
     def _capture_segments(self, st, B: int, policy: bool, order: Sequence[int]) -> list:
         """Runs _update_body under stream capture, cutting the capture at every all-reduce point:
