@@ -23,6 +23,7 @@
 #include "common.h"
 #include "mfma_tiles.h"
 
+#include <mutex>
 #include <type_traits>
 
 namespace hhrl {
@@ -1826,6 +1827,58 @@ int hhrl_vae_learn_step(float* params, float* grads, float* m, float* v, const l
   HHRL_REQUIRE(step >= 1, "vae_learn_step: step=%d", step);
   const AdamK k = make_adam_k(lr, beta1, beta2, adam_eps, step, 1.0);
   return vae_step_impl(params, grads, m, v, &k, offsets, n_flat, data, eps, B, N, g, recon_scale, loss, ws, stream);
+}
+
+// ---------------------------------------------------------------- a training step that allocates nothing
+// For callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+// harnesses that forbid it): hhrl_vae_train_step with its workspace in a file-scope device array instead of
+// a caller-provided buffer.  Every GPU the library runs on holds its own copy of the array until the process
+// ends; the array's name is only a host-side handle, so its device address is looked up once per device
+// (hipGetSymbolAddress with that device current) and that address is what the kernels and the memset get.
+static __device__ __align__(256) float scratch[HHRL_VAE_SCRATCH_FLOATS];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+float* g_scratch_ptr[kMaxDevices];          // device address of `scratch` on device d (nullptr: not looked up yet)
+long g_scratch_shape[kMaxDevices][4];       // (B, N, g, n_flat) of the last call on device d: the layout the array holds
+}  // namespace
+
+int hhrl_vae_train_step_noalloc(const float* params, float* grads, const long* offsets, long n_flat, const float* data,
+                                const float* eps, int B, int N, int g, float recon_scale, float* loss, void* stream) {
+  HHRL_REQUIRE(B > 0 && N > 0 && g > 0 && n_flat > 0, "vae_train_step_noalloc: bad shape B=%d N=%d g=%d n_flat=%ld", B, N, g, n_flat);
+  const long need = carve(nullptr, B, N, g, n_flat).total;
+  HHRL_REQUIRE(need <= (long)HHRL_VAE_SCRATCH_FLOATS,
+               "vae_train_step_noalloc: B=%d lanes x N=%d cars needs %ld workspace floats, the built-in scratch holds %ld "
+               "(use hhrl_vae_train_step with a workspace of your own for larger batches)",
+               B, N, need, (long)HHRL_VAE_SCRATCH_FLOATS);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return fail(HHRL_ERR_HIP, "vae_train_step_noalloc: hipGetDevice failed");
+  HHRL_REQUIRE(dev >= 0 && dev < kMaxDevices, "vae_train_step_noalloc: device %d out of range", dev);
+  hipStream_t st = as_stream(stream);
+  float* ws = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (g_scratch_ptr[dev] == nullptr) {
+      float* p = nullptr;
+      const hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(scratch));
+      if (e != hipSuccess || p == nullptr)
+        return fail(HHRL_ERR_HIP, "vae_train_step_noalloc: hipGetSymbolAddress(scratch) on device %d: %s", dev, hipGetErrorString(e));
+      g_scratch_ptr[dev] = p;
+    }
+    ws = g_scratch_ptr[dev];
+    // The array keeps the last call's contents.  The step reads the layout's padding (slab columns nobody
+    // writes) as zeros, and another (B, N, g, n_flat) carves the array differently: clear the part this
+    // call uses whenever the shape differs from the one the array was last carved for.
+    long* sh = g_scratch_shape[dev];
+    if (sh[0] != B || sh[1] != N || sh[2] != g || sh[3] != n_flat) {
+      if (hipMemsetAsync(ws, 0, (size_t)need * sizeof(float), st) != hipSuccess)
+        return fail(HHRL_ERR_HIP, "vae_train_step_noalloc: clearing the scratch array failed");
+      sh[0] = B; sh[1] = N; sh[2] = g; sh[3] = n_flat;
+    }
+  }
+  return vae_step_impl(const_cast<float*>(params), grads, nullptr, nullptr, nullptr, offsets, n_flat, data, eps, B, N, g,
+                       recon_scale, loss, ws, stream);
 }
 
 static int lane_layers(LaneArgs& la, const float* params, const long* offsets, long n_flat, int g, const char* who) {

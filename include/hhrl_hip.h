@@ -162,6 +162,20 @@ int hhrl_vae_learn_step(float* params, float* grads, float* m, float* v, const l
                         double lr, double beta1, double beta2, double adam_eps, int step,
                         float* loss, float* ws, void* stream);
 
+/* hhrl_vae_train_step for callers that CANNOT ALLOCATE device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and
+ * results as hhrl_vae_train_step (bit for bit) without `ws`: the workspace is a device array built into the
+ * library, HHRL_VAE_SCRATCH_FLOATS floats (8 MiB) per GPU, held by every GPU the library runs on until the
+ * process ends.  The call allocates and frees nothing.  Limit: hhrl_vae_workspace_floats(B, N, g, n_flat)
+ * must not exceed HHRL_VAE_SCRATCH_FLOATS (every chunk of the reference's training script fits: 64 lanes of
+ * up to 59 cars need 1.2 M floats); larger batches are rejected with HHRL_ERR_ARG and a message.  All calls
+ * on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) race; the part
+ * of the array a call uses is cleared when its shape differs from the previous call's on that GPU. */
+#define HHRL_VAE_SCRATCH_FLOATS (2 * 1024 * 1024)
+int hhrl_vae_train_step_noalloc(const float* params, float* grads, const long* offsets, long n_flat,
+                                const float* data, const float* eps, int B, int N, int g,
+                                float recon_scale, float* loss, void* stream);
+
 /* Inference, one launch each.
  * Encoder.encode / DeepSetEncoder.forward (algorithm.py:40-47, 109-116) for B lanes:
  *   cars [total][2] (location, speed); lane_start [B+1] device ints = first car of every lane
