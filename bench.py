@@ -60,6 +60,15 @@ def vae_executed_flops_per_lane(N: int, g: int) -> float:
     return 2.0 * (lane + car * N)
 
 
+def progress(msg: str) -> None:
+    """One line on stderr from rank 0: a long run shows where it is (stdout carries the JSON line only)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %6.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
 def synth_lanes(B: int, N: int, seed: int) -> np.ndarray:
     rs = np.random.RandomState(seed)
     x = rs.uniform(0.0, 1.0, size=(B, N, 1))
@@ -154,8 +163,10 @@ def agent_update_rates(device, steps: int, group=None, world: int = 1, cpu_basel
     batch named is PER RANK (weak scaling): a global minibatch of world x batch rows, one gradient all-reduce
     per optimizer step; time = max over ranks."""
     import torch.distributed as dist
+    from hhrl_vae_amd import dist as hdist
     out = {}
     for name, kind, batch, n_rows in AGENT_CASES:
+        progress("agent updates: %s%s" % (name, " x %d ranks" % world if group is not None else ""))
         net = _agent_net(kind, batch, n_rows, device, group)
         rank = dist.get_rank(group) if group is not None else 0
         rows = np.random.RandomState(3407 + rank).uniform(0, 1, size=(n_rows, net.fam.row_width))
@@ -172,9 +183,7 @@ def agent_update_rates(device, steps: int, group=None, world: int = 1, cpu_basel
             forms = net.launch_forms()
             done = it >= 30 and len(forms) == 1 + n_orders and "tuning" not in forms.values()
             if group is not None:
-                flag = torch.tensor([1.0 if done else 0.0], device=device)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-                done = bool(flag.item() > 0.5)
+                done = hdist.reduce_scalar(1.0 if done else 0.0, "min", group, device) > 0.5
             if done:
                 break
         # ... and until the device has been busy with this update for half a second: the update chains that
@@ -190,22 +199,20 @@ def agent_update_rates(device, steps: int, group=None, world: int = 1, cpu_basel
         torch.cuda.synchronize()
         n_timed = max(steps, int(0.25 * n_w / (time.perf_counter() - t_w)))          # at least a quarter of a second
         if group is not None:
-            cnt = torch.tensor([float(n_timed)], device=device)
-            dist.all_reduce(cnt, op=dist.ReduceOp.MAX, group=group)
-            n_timed = int(cnt.item())
+            n_timed = int(hdist.reduce_scalar(float(n_timed), "max", group, device))
+            torch.cuda.synchronize()
             dist.barrier(group=group)
             torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n_timed):
             net.learn()
+        torch.cuda.synchronize()
         if group is not None:
             dist.barrier(group=group)
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if group is not None:
-            tt = torch.tensor([dt], device=device, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=group)
-            dt = float(tt.item())
+            dt = hdist.reduce_scalar(dt, "max", group, device)
         w = work.td3_update(net.fam, batch)
         out[name] = {"minibatches_per_s": n_timed / dt, "ms_per_update": 1e3 * dt / n_timed,
                      "rows_per_s": world * n_timed * net.batch_size / dt, "updates_timed": n_timed,
@@ -233,6 +240,7 @@ def agent_update_rates(device, steps: int, group=None, world: int = 1, cpu_basel
         del net
     if cpu_baseline and group is None:
         for name, kind, batch, _ in AGENT_CASES:
+            progress("CPU oracle: " + name)
             out[name]["cpu_baseline"] = cpu_baseline_td3(kind, batch, 4.0 if batch <= 64 else 6.0)
     return out
 
@@ -342,6 +350,10 @@ def main() -> None:
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args, sys.argv[1:]))
 
+    wd = float(os.environ.get("HHRL_BENCH_WATCHDOG", "0"))
+    if wd > 0:                      # diagnostic: a rank still running after that many seconds says where and exits
+        import faulthandler
+        faulthandler.dump_traceback_later(wd, exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -374,11 +386,14 @@ def main() -> None:
     x = torch.from_numpy(synth_lanes(B, N, 3407 + rank)).to(device)
     gcount = B * N * world
 
+    from hhrl_vae_amd import dist as hdist
+
     def barrier():
+        torch.cuda.synchronize()
         if group is not None:
             import torch.distributed as dist
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     def timed_window(k: int) -> float:
         """K steps between barriers; max over ranks."""
@@ -388,13 +403,9 @@ def main() -> None:
             enc.learn(x, sync=False, global_count=gcount)
         barrier()
         d = time.perf_counter() - t0
-        if group is not None:
-            import torch.distributed as dist
-            t = torch.tensor([d], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            d = float(t.item())
-        return d
+        return hdist.reduce_scalar(d, "max", group, device)
 
+    progress("VAE step: %d lanes x %d cars, latent %d, %d rank(s)" % (B, N, g, world))
     for _ in range(args.warmup):
         enc.learn(x, sync=False, global_count=gcount)
     dt = timed_window(args.steps)                       # THE timed region: exactly --steps steps
@@ -496,6 +507,7 @@ def main() -> None:
         if world == 1 and not args.no_agents:
             out["inference"] = inference_latency(enc, device)
         if world == 1 and not args.no_cpu_baseline:
+            progress("CPU oracle: VAE step")
             out["cpu_baseline"] = cpu_baseline_vae(B, N, g)
         print(json.dumps(out))
     if group is not None:

@@ -31,21 +31,51 @@ def shard_bounds(n_rows: int, rank: int, world_size: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+_host_staged = {}
+
+
+def host_staged(group) -> bool:
+    """True for a gloo group.  gloo is the backend of CPU tests and of rehearsals of the N-rank path with
+    several ranks on one GPU (RCCL is the production backend).  Its own handling of device tensors (side
+    streams, events, pinned staging buffers) was seen to stall when several processes share one GPU, so
+    device tensors never reach it: the helpers below copy them to the host, reduce there, and copy back.
+    RCCL collectives take the device tensor and queue behind the kernels on the launch stream."""
+    key = id(group)
+    v = _host_staged.get(key)
+    if v is None:
+        import torch.distributed as dist
+        v = _host_staged[key] = str(dist.get_backend(group)) == "gloo"
+    return v
+
+
 def global_count(local_count: int, group, device=None) -> int:
     """Sum of `local_count` over the group (one tiny all-reduce + host read)."""
+    return int(round(reduce_scalar(float(local_count), "sum", group, device)))
+
+
+def reduce_scalar(value: float, op: str, group, device=None) -> float:
+    """`value` reduced over the group with op in {"sum", "min", "max"} and read back on the host: the
+    control-plane reductions of a data-parallel run (element counts, agreed step counts, the slowest rank's
+    time).  One tiny all-reduce + a host read; the tensor lives on `device` (RCCL reduces device tensors only)."""
     if group is None:
-        return int(local_count)
+        return float(value)
     import torch.distributed as dist
-    t = torch.tensor([float(local_count)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, group=group)
-    return int(round(float(t.item())))
+    ops = {"sum": dist.ReduceOp.SUM, "min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX}
+    t = torch.tensor([float(value)], dtype=torch.float64, device=None if host_staged(group) else device)
+    dist.all_reduce(t, op=ops[op], group=group)
+    return float(t.item())
 
 
 def allreduce_sum_(flat: torch.Tensor, group) -> torch.Tensor:
     """In-place SUM all-reduce of one flat fp32 bucket (no-op without a group)."""
     if group is not None:
         import torch.distributed as dist
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if flat.is_cuda and host_staged(group):
+            h = flat.detach().cpu()                   # waits for the launch stream
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            flat.copy_(h)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat
 
 
@@ -58,6 +88,6 @@ def broadcast_ints(values, group, device=None):
     if group is None:
         return vals
     import torch.distributed as dist
-    t = torch.tensor(vals, dtype=torch.int64, device=device)
+    t = torch.tensor(vals, dtype=torch.int64, device=None if host_staged(group) else device)
     dist.broadcast(t, src=dist.get_global_rank(group, 0), group=group)
     return [int(v) for v in t.cpu().tolist()]

@@ -691,20 +691,12 @@ class TD3Learner:
             segs = self._capture_segments(st, B, policy, order)
             self._seg_graphs[key] = segs
         dbg = _DP_DEBUG
-        # The gloo backend (CPU rehearsals and tests of the N-rank path; RCCL is the production backend) stages
-        # device tensors through the host on streams of its own and waits for the launch stream anyway.  Handing
-        # it a stream with a freshly launched graph still in flight was seen to stall that hand-over when several
-        # processes share one GPU, so the launch stream is drained first; for RCCL the collective simply queues
-        # behind the graph on the same stream.
-        drain = self._group_backend == "gloo"
         for n, (graph, flat) in enumerate(segs):
             graph.replay()
             if dbg:
                 torch.cuda.synchronize()
                 print("[dp rank %d] it %d key %s segment %d/%d replayed" % (self.rank, self.total_it, key[1:3], n, len(segs)), flush=True)
             if flat is not None:
-                if drain:
-                    _lib.current_stream().synchronize()
                 hdist.allreduce_sum_(flat, self.group)
                 if dbg:
                     torch.cuda.synchronize()

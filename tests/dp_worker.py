@@ -1,4 +1,4 @@
-"""One rank of the world-size-2 data-parallel tests (tests/test_gpu_dp_world2.py starts two of these as fresh
+"""One rank of the world-size-2 data-parallel tests (tests/test_zy_dp_world2.py starts two of these as fresh
 child processes).  Both ranks use cuda:0 and exchange gradients over the gloo backend: the PRODUCT classes run
 with a real group of two, each on its shard of a global minibatch, and write what they end up with.
 
