@@ -10,7 +10,7 @@ import torch
 
 import gen
 import hhrl_oracle as O
-from golden_util import assert_close, load_case, sub, td3_inputs
+from golden_util import adam_path_close, assert_close, load_case, sub, td3_inputs
 from test_gpu_kernels import scaled_close
 
 pytestmark = pytest.mark.gpu
@@ -104,6 +104,62 @@ def test_td3_golden(case):
             scaled_close("choose/" + n, out, fx["choose/%s/out" % n], atol_rel=5e-6)
         if "policy/out" in fx:
             scaled_close("policy", net.policy(fx["policy/o"], fx["policy/g"]), fx["policy/out"], atol_rel=5e-6)
+
+
+@pytest.mark.parametrize("kind,batch", [("worker", 4096), ("triple", 1024)])
+def test_td3_benched_batch_sizes_vs_oracle(kind, batch):
+    """The batch sizes bench.py times beside the reference's 64 -- WorkerTD3 at 4096 rows and HATD3Triple at
+    1024 -- against the CPU oracle on identical weights, rows, indices, noise and actor order: two calls, the
+    second a policy step.  At these sizes other kernels run than at batch 64 (device-resident replay and its
+    gather, the large-tile GEMM, weight gradients split over the rows with float atomics).  Bars: loss and
+    gradients rtol 1e-4 with a floor of 1e-5 of the tensor's largest entry (sums over up to 4096 rows in a
+    different order), parameters by golden_util.adam_path_close from the oracle's gradients."""
+    import hhrl_vae_amd.algorithm as A
+    cfg = gen.cav_cfg(cap=8192, batch=batch) if kind == "worker" else gen.light_cfg(cap=2048, batch=batch)
+    net = A.WorkerTD3(cfg) if kind == "worker" else A.HATD3Triple(cfg)
+    assert net.device_replay
+    ofam = O.family_from_cfg(kind, cfg)
+    names = net.actor_names
+    t = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}
+    a_init = [gen.gen_state(O.actor_param_shapes(ofam, k), 400 + k) for k in range(len(names))]
+    c_init = gen.gen_state(O.critic_param_shapes(ofam), 410)
+    oracle = O.TD3(ofam, [t(a) for a in a_init], t(c_init))
+    net.load_state_dicts(dict(zip(names, a_init), critic=c_init))
+    n_rows = net.memory.shape[0]
+    rows = gen.gen_rows(n_rows, net.fam.row_width, 411)
+    net.memory[:] = rows
+    net.pointer = n_rows
+    rs = np.random.RandomState(412)
+    glog = {n: [] for n in names + ["critic"]}
+    lrlog = {n: [] for n in names + ["critic"]}
+    for call in range(2):
+        idx = rs.randint(0, n_rows, size=batch)
+        noise = [rs.standard_normal((batch, a)).astype(np.float32) for a in net.fam.a_dims]
+        order = list(rs.permutation(len(names)))
+        lr_c, lr_a = oracle.critic_opt.lr, [o.lr for o in oracle.actor_opts]
+        out = oracle.learn(O.split_rows(ofam, rows[idx]), [torch.from_numpy(n) for n in noise], order)
+        net.learn(indices=idx, noise=noise, order=order)
+        pre = "%s_b%d/call%d" % (kind, batch, call)
+        mse = net.last_critic_loss.cpu().numpy()
+        assert_close(pre + "/critic_loss", float(mse[0] + mse[1]), out["critic_loss"], rtol=1e-4, atol=0)
+        for k, w in out["critic_grads"].items():
+            scaled_close(pre + "/grad/critic/" + k, net.critic.opt.g[k].cpu().numpy(), w.numpy(), rtol=1e-4, atol_rel=1e-5)
+        glog["critic"].append({k: v.numpy() for k, v in out["critic_grads"].items()})
+        lrlog["critic"].append(lr_c)
+        # the last actor stepped still holds its gradient (an earlier one's buffer is intact too: zeroed per actor)
+        for i, g in out.get("actor_grads", {}).items():
+            for k, w in g.items():
+                scaled_close("%s/grad/%s/%s" % (pre, names[i], k), net.actors[i].opt.g[k].cpu().numpy(), w.numpy(),
+                             rtol=1e-4, atol_rel=2e-5)
+            glog[names[i]].append({k: v.numpy() for k, v in g.items()})
+            lrlog[names[i]].append(lr_a[i])
+    np_ = lambda d: {k: v.detach().cpu().numpy() for k, v in d.items()}
+    sds, tgt = net.state_dicts(), net.target_state_dicts()
+    adam_path_close("critic", np_(sds["critic"]), np_(oracle.critic), glog["critic"], lrlog["critic"], g_floor=1e-5)
+    adam_path_close("critic_target", np_(tgt["critic"]), np_(oracle.critic_target), glog["critic"], lrlog["critic"], g_floor=1e-5)
+    for i, n in enumerate(names):
+        adam_path_close(n, np_(sds[n]), np_(oracle.actors[i]), glog[n], lrlog[n], g_floor=2e-5)
+        adam_path_close(n + "_target", np_(tgt[n]), np_(oracle.actor_targets[i]), glog[n], lrlog[n], g_floor=2e-5)
 
 
 def test_td3_store_and_sample_surface():
@@ -236,7 +292,8 @@ def test_td3_device_replay_default():
     assert not A.WorkerTD3(gen.cav_cfg(cap=64)).device_replay
     assert A.WorkerTD3(gen.cav_cfg(cap=64, batch=4096)).device_replay
     assert not A.HATD3Triple(gen.light_cfg(cap=64), device_replay=False).device_replay
-    assert not A.ManagerTD3(gen.light_cfg(cap=64, batch=4096)).device_replay or True      # dict replay: host gather whatever the flag
+    m = A.ManagerTD3(gen.light_cfg(cap=64, batch=4096))                 # dict replay: no device mirror to gather from,
+    assert not hasattr(m, "_dev_mem") and not hasattr(m, "_sync_replay")   # the host gather is used whatever the flag says
 
 
 def test_td3_checkpoint_roundtrip(tmp_path):

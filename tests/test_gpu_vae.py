@@ -187,7 +187,7 @@ def adam_conditioned_close(name, got_p, want_p, want_g, lr, g_floor, rtol=1e-4):
         assert np.all(err <= tol), "%s/%s: %d elements out, worst excess %.3e" % (name, k, int((err > tol).sum()), float((err - tol).max()))
 
 
-@pytest.mark.parametrize("B,N,g", [(4096, 7, 4), (4096, 30, 4), (1000, 3, 16)])
+@pytest.mark.parametrize("B,N,g", [(4096, 7, 4), (4096, 30, 4), (1000, 3, 16), (4096, 30, 2), (4096, 30, 8), (4096, 30, 16)])
 def test_vae_full_size_vs_oracle(B, N, g):
     """Benchmark batch sizes (4096 lanes x 7 and x 30 cars): loss, every gradient, Adam moments and updated
     parameters against the CPU oracle on identical inputs, for two consecutive
