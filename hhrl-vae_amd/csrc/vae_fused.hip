@@ -35,7 +35,7 @@ using namespace mt;
 // Diagnostic builds (-DHHRL_STAMPS) record the shader clock of workgroup 0, thread 0
 // at marked points of the fused kernels; hhrl_debug_stamps() copies them out.
 #ifdef HHRL_STAMPS
-__device__ long long g_stamps[3][64];
+__device__ long long g_stamps[4][64];
 #define HHRL_STAMP(k, i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[k][i] = clock64(); } while (0)
 #else
 #define HHRL_STAMP(k, i) do { } while (0)
@@ -1616,6 +1616,894 @@ __global__ __launch_bounds__(256) void vae_reduce_grads_kernel(const float* __re
   }
 }
 
+// Workgroup barrier for hand-offs through LDS only: waits for this wave's LDS traffic, not for its global
+// loads, so that requests issued before the barrier stay in flight across it (__syncthreads() would wait for
+// them: its fence covers global memory too).  Only for phases that exchange nothing through global memory.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+
+// ===================================================================== the whole step in one launch
+// One workgroup (eight waves) owns tiles of 16 traffic lanes TOGETHER WITH their cars and runs the whole
+// chain for a tile without leaving the CU: per-lane forward (16-row products on 16x16x4 matrix
+// instructions, every wave owning output blocks), the lane's cars (one tile of 16 cars per wave and round,
+// func.0 in factored form exactly as in the per-car kernel above), per-lane backward.  What the four-launch
+// form passes through global memory stays in LDS or registers here: the saved activations of the lanes,
+// U (func.0's pre-activation per lane), S (df1 summed per lane).  The lane weights (86 KB) and the cars' images
+// (83 KB) do not fit LDS together, so they share a region: the weights are staged for the forward chain,
+// give way to the car phase, and are requested again from L2 under the end of the car phase.
+// func.2's weight gradient is formed across the waves (every wave owns two 16x16 blocks of it and walks all
+// waves' df2 / f1 images), so there is no per-wave copy of it to combine.  With at most 256 tiles the grid
+// covers the batch; beyond that a workgroup loops over tiles and keeps every weight-gradient block in
+// registers.  Gradients leave as one slab per workgroup; vae_reduce_grads_kernel sums the slabs in a fixed
+// order (and applies Adam): the same inputs give the same bits.
+struct StepArgs {
+  const float* data;   // [B*N][2]
+  const float* eps;    // [B][g]
+  const float* params; // flat parameter buffer; layer l's weight at params + ow[l], bias at params + ob[l]
+  int ow[NLAYER], ob[NLAYER];
+  int total;           // floats per slab (= flat buffer length)
+  float* aux;          // out (workgroup 0): wloc[32] bloc[32] as the step found them, at aux + 128
+  float* slab;         // [gridDim.x][total]
+  float* loss_part;    // [gridDim.x]
+  float* kl_part;      // [gridDim.x]
+  int B, N, g, tiles, R;   // tiles of ST_ROWS lanes; R = most traffic lanes a car tile can touch
+  float recon_scale;
+};
+
+__device__ __forceinline__ const float* lane_bias_src_step(const StepArgs& g, int idx) {
+  const int gd = g.g;
+  const float* p = g.params;
+  if (idx < LB_RHO0) return p + g.ob[PHI2] + idx;
+  if (idx < LB_RHO2) return p + g.ob[RHO0] + (idx - LB_RHO0);
+  if (idx < LB_HEAD) return p + g.ob[RHO2] + (idx - LB_RHO2);
+  if (idx < LB_DEC0) {
+    const int c = idx - LB_HEAD;
+    return c < gd ? p + g.ob[MEAN] + c : (c < 2 * gd ? p + g.ob[LOGVAR] + (c - gd) : nullptr);
+  }
+  if (idx < LB_DEC2) return p + g.ob[DEC0] + (idx - LB_DEC0);
+  if (idx < LB_END) return p + g.ob[DEC2] + (idx - LB_DEC2);
+  return nullptr;
+}
+
+constexpr int ST_ROWS = 16, ST_NT = 512, ST_WAVES = 8;
+// LDS map (floats).  Permanent part:
+constexpr int FS_W2 = 0;                            // [32][129] func.2
+constexpr int FS_SMALL = FS_W2 + 32 * 129;          // b2[32] w4[32] b4[1]
+constexpr int FS_BIAS = FS_SMALL + 96;              // lane biases (LB_* map), then q[128] and p[128]
+constexpr int FB_Q = LB_END, FB_P = LB_END + 128, FB_PHI0 = LB_END + 256, FB_ALL = LB_END + 256 + 48;   // phi.0: w[16][2] then b[16]
+constexpr int FS_H1 = FS_BIAS + FB_ALL;             // [16][33]  summed hidden of phi (16 columns used)
+constexpr int FS_POOL = FS_H1 + 16 * 33;            // [16][33]
+constexpr int FS_R1 = FS_POOL + 16 * 33;            // [16][129]
+constexpr int FS_R2 = FS_R1 + 16 * 129;             // [16][65]
+constexpr int FS_ML = FS_R2 + 16 * 65;              // [16][33]  mean | logvar, later dpooled
+constexpr int FS_Z = FS_ML + 16 * 33;               // [16][17]
+constexpr int FS_D1 = FS_Z + 16 * 17;               // [16][129]
+constexpr int FS_D2 = FS_D1 + 16 * 129;             // [16][33]
+constexpr int FS_DML = FS_D2 + 16 * 33;             // [16][33]
+constexpr int FS_TMP = FS_DML + 16 * 33;            // [16][33]
+constexpr int FS_CARS = FS_TMP + 16 * 33;           // 16 lanes x N x 2 (N <= STAGE_MAX_CARS)
+constexpr int FS_OVL = ((FS_CARS + 2 * ST_ROWS * STAGE_MAX_CARS + 3) / 4) * 4;
+// Shared part, by phase.  Lane phases: the weight images (LW_* map from FS_OVL, LW_BIAS floats), then a spare
+// area.  Car phase: U [16][129] (afterwards S in its place), then one image block per wave.
+constexpr int FO_U = 0, FO_WAVE0 = 16 * 129;
+constexpr int FO_SPARE = LW_BIAS;                   // behind the weight images: the four partial products of dz
+constexpr int FO_END = FO_WAVE0 + ST_WAVES * CAR_WAVE_FLOATS;
+static_assert(FS_OVL % 4 == 0 && FO_WAVE0 % 4 == 0 && CAR_WAVE_FLOATS % 4 == 0, "16-byte aligned regions");
+static_assert(FO_SPARE + 4 * 16 * 17 <= FO_END, "partial products of dz fit behind the weight images");
+static_assert(16 * 128 <= CAR_WAVE_FLOATS, "a wave's image block holds its per-lane sums");
+constexpr int ST_LDS_FLOATS = FS_OVL + FO_END;
+static_assert(ST_LDS_FLOATS * 4 <= 163840 - 64, "the one-launch step must fit the 160 KiB LDS");
+
+__device__ __forceinline__ float colsum16(const float* img, int ld, int col) {
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int rr = 0; rr < 16; rr += 2) {
+    s0 += img[rr * ld + col];
+    s1 += img[(rr + 1) * ld + col];
+  }
+  return s0 + s1;
+}
+
+// SINGLE: the grid covers every tile (up to 256 tiles = 4096 traffic lanes): the tile loop runs once and no
+// gradient block has to live in a register across the car phase.
+template <bool SINGLE>
+__global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NT = ST_NT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, q = lane >> 4;            // 16x16 blocks: column j, rows 4 q + reg
+  const int r32 = lane & 31, h32 = lane >> 5;
+  const int gd = g.g;
+  float* W2s = lds + FS_W2;
+  float* b2s = lds + FS_SMALL;
+  float* w4s = b2s + 32;
+  float* b4s = w4s + 32;
+  float* bs = lds + FS_BIAS;
+  float* Ih1 = lds + FS_H1;
+  float* Ipool = lds + FS_POOL;
+  float* Ir1 = lds + FS_R1;
+  float* Ir2 = lds + FS_R2;
+  float* Iml = lds + FS_ML;
+  float* Iz = lds + FS_Z;
+  float* Id1 = lds + FS_D1;
+  float* Id2 = lds + FS_D2;
+  float* Idml = lds + FS_DML;
+  float* Itmp = lds + FS_TMP;
+  float* Icars = lds + FS_CARS;
+  float* ovl = lds + FS_OVL;                         // weight images (LW_* offsets) or U | wave images
+  float* Iu = ovl + FO_U;
+  float* wl = ovl + FO_WAVE0 + wave * CAR_WAVE_FLOATS;
+  float* f1i = wl + CAR_F1;
+  float* f2i = wl + CAR_F2;
+  float* dpre = wl + CAR_ROW;
+  const bool staged = g.N <= STAGE_MAX_CARS;
+  HHRL_STAMP(3, 0);
+
+  // ---- requests of the prologue: everything is asked for before the first LDS write
+  RegsP<NT> rP;
+  RegsR<NT> rR;
+  RegsD<NT> rD;
+  float rBias[1];
+  auto request_weights = [&](int tid) {
+    request_w4<128, 32, W4Map<128, 32, NT>::STEPS, NT>(rP.rho0, (g.params + g.ow[RHO0]), tid);
+    rP.phi2 = tid < 128 ? reinterpret_cast<const float4*>((g.params + g.ow[PHI2]))[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+    request_w4<64, 128, W4Map<64, 128, NT>::STEPS, NT>(rR.rho2, (g.params + g.ow[RHO2]), tid);
+    const int nh = 128 * gd;
+#pragma unroll
+    for (int u = 0; u < 2048 / NT; ++u) {
+      const int e = u * NT + tid;
+      rR.head[u] = e < nh ? (e < 64 * gd ? (g.params + g.ow[MEAN])[e] : (g.params + g.ow[LOGVAR])[e - 64 * gd]) : 0.f;
+    }
+    request_w4<32, 128, W4Map<32, 128, NT>::STEPS, NT>(rD.dec2, (g.params + g.ow[DEC2]), tid);
+#pragma unroll
+    for (int u = 0; u < 2048 / NT; ++u) {
+      const int e = u * NT + tid;
+      rD.dec0[u] = e < nh ? (g.params + g.ow[DEC0])[e] : 0.f;
+    }
+  };
+  auto commit_weights = [&](int tid) {
+    commit_w4<128, 32, W4Map<128, 32, NT>::STEPS, NT>(ovl + LW_RHO0, 33, rP.rho0, tid);
+    if (tid < 128) commit4<16>(ovl + LW_PHI2, 17, tid, rP.phi2);
+    commit_w4<64, 128, W4Map<64, 128, NT>::STEPS, NT>(ovl + LW_RHO2, 129, rR.rho2, tid);
+    const int nh = 128 * gd, lg = __ffs(gd) - 1;
+#pragma unroll
+    for (int u = 0; u < 2048 / NT; ++u) {
+      const int e = u * NT + tid;
+      if (e < nh) ovl[LW_HEAD + (e >> 6) * 65 + (e & 63)] = rR.head[u];
+    }
+    for (int i = tid; i < 32 * 65; i += NT)
+      if (i / 65 >= 2 * gd) ovl[LW_HEAD + i] = 0.f;
+    commit_w4<32, 128, W4Map<32, 128, NT>::STEPS, NT>(ovl + LW_DEC2, 129, rD.dec2, tid);
+#pragma unroll
+    for (int u = 0; u < 2048 / NT; ++u) {
+      const int e = u * NT + tid;
+      if (e < nh) ovl[LW_DEC0 + (e >> lg) * 17 + (e & (gd - 1))] = rD.dec0[u];
+    }
+    for (int i = tid; i < 128 * 17; i += NT)
+      if (i % 17 >= gd) ovl[LW_DEC0 + i] = 0.f;
+  };
+  // the tile's car states: 16 lanes x N x 2 floats (N <= STAGE_MAX_CARS), one float per thread
+  auto request_cars16 = [&](int row0) -> float {
+    const long base = (long)row0 * g.N * 2, lim = (long)g.B * g.N * 2;
+    const int n = staged ? 2 * ST_ROWS * g.N : 0;
+    return (tid < n && base + tid < lim) ? g.data[base + tid] : 0.f;
+  };
+  auto commit_cars16 = [&](float v) {
+    if (staged && tid < 2 * ST_ROWS * g.N) Icars[tid] = v;
+  };
+
+  // the position part of func.0, by the last 128 threads (output o each): p = E wloc, q = b0 + E bloc with
+  // E = W0[:, 32:].  Its loads go first, so that they have arrived when the rest of the requests has been issued.
+  const int o_pq = tid - (NT - 128);
+  float4 pq_e[8], pq_w[8], pq_b[8];
+  float pq_b0 = 0.f;
+  if (o_pq >= 0) {
+    const float4* src = reinterpret_cast<const float4*>((g.params + g.ow[FUNC0]) + o_pq * 64 + 32);
+    const float4* wl4 = reinterpret_cast<const float4*>(g.params + g.ow[LOC]);
+    const float4* bl4 = reinterpret_cast<const float4*>(g.params + g.ob[LOC]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      pq_e[e] = src[e];
+      pq_w[e] = wl4[e];
+      pq_b[e] = bl4[e];
+    }
+    pq_b0 = (g.params + g.ob[FUNC0])[o_pq];
+  }
+  const float phi0_v = tid < 32 ? (g.params + g.ow[PHI0])[tid] : (tid < 48 ? (g.params + g.ob[PHI0])[tid - 32] : 0.f);
+  {
+    const float* src = lane_bias_src_step(g, tid);
+    rBias[0] = src ? *src : 0.f;
+  }
+  request_weights(tid);
+  float4 v2[2];
+  request_w4<32, 128, 2, NT>(v2, (g.params + g.ow[FUNC2]), tid);
+  const float p_b2 = (g.params + g.ob[FUNC2])[r32], p_w4 = (g.params + g.ow[FUNC4])[r32], p_b4 = (g.params + g.ob[FUNC4])[0];
+  float car0 = request_cars16(blockIdx.x * ST_ROWS);
+  // func.0's columns for d2 (A = W0[:, :32]) as the B operand of U = d2 A^T: output column 16 wave + j,
+  // step s takes k = 4 s + q
+  float w0u[8];
+  {
+    const float* src = (g.params + g.ow[FUNC0]) + (16 * wave + j) * 64 + q;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) w0u[s] = src[4 * s];
+  }
+  if (o_pq >= 0) {
+    float pv = 0.f, qv = pq_b0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      pv += pq_e[e].x * pq_w[e].x + pq_e[e].y * pq_w[e].y + pq_e[e].z * pq_w[e].z + pq_e[e].w * pq_w[e].w;
+      qv += pq_e[e].x * pq_b[e].x + pq_e[e].y * pq_b[e].y + pq_e[e].z * pq_b[e].z + pq_e[e].w * pq_b[e].w;
+    }
+    bs[FB_Q + o_pq] = qv;
+    bs[FB_P + o_pq] = pv;
+  }
+  if (tid < 48) bs[FB_PHI0 + tid] = phi0_v;
+  if (tid < LB_END) bs[tid] = rBias[0];
+  commit_weights(tid);
+  commit_w4<32, 128, 2, NT>(W2s, 129, v2, tid);
+  if (tid < 32) {
+    b2s[tid] = p_b2;
+    w4s[tid] = p_w4;
+  }
+  if (tid == 0) b4s[0] = p_b4;
+  commit_cars16(car0);
+  if (blockIdx.x == 0 && tid < 64) g.aux[128 + tid] = tid < 32 ? (g.params + g.ow[LOC])[tid] : (g.params + g.ob[LOC])[tid - 32];
+  lds_barrier();
+  HHRL_STAMP(3, 1);
+
+  // ---- what a workgroup keeps in registers across its tiles
+  // weight-gradient blocks (16x16) of the per-lane layers owned by this wave
+  f32x4 aF0[2], aDec2[2], aDec0, aHead, aRho2[4], aRho0[2], aPhi2;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  aF0[0] = aF0[1] = aDec2[0] = aDec2[1] = aDec0 = aHead = aRho0[0] = aRho0[1] = aPhi2 = zero4;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) aRho2[t] = zero4;
+  float bDec2 = 0.f, bDec0 = 0.f, bHead = 0.f, bRho2 = 0.f, bRho0 = 0.f, bPhi2 = 0.f;
+  float gPhi0 = 0.f;                                  // threads 0..47: dW_phi0[k][0], dW_phi0[k][1], db_phi0[k]
+  float klacc = 0.f;
+  // per-car layers: func.2's weight gradient (two blocks per wave), column sums of df1, func.4, the loss
+  f32x4 dW2a[2];
+  dW2a[0] = dW2a[1] = zero4;
+  float db0[8], sacc[8];
+#pragma unroll
+  for (int blk = 0; blk < 8; ++blk) db0[blk] = sacc[blk] = 0.f;
+  float w4acc = 0.f, db2acc = 0.f, b4acc = 0.f, lossacc = 0.f;
+
+  // With one tile per workgroup (SINGLE) a layer's slab entries are written right after the phase that completes
+  // them, under the later phases, and no gradient block lives in a register longer than its phase.
+  float* slab = g.slab + (long)blockIdx.x * g.total;
+  auto put16 = [&](long base, int ld, int row0, int row_lim, int col0, int col_lim, const f32x4& t) {
+    const int col = col0 + j;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = row0 + 4 * q + e;
+      if (row < row_lim && col < col_lim) slab[base + (long)row * ld + col] = t[e];
+    }
+  };
+  const int bt = tid - 256;                            // owner index of the bias-gradient column sums
+  auto write_f0 = [&]() {
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) put16(g.ow[FUNC0], 64, 16 * wave, 128, 16 * cb, 32, aF0[cb]);
+  };
+  auto write_dec2 = [&]() {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) put16(g.ow[DEC2], 128, 16 * rb, 32, 16 * wave, 128, aDec2[rb]);
+    if (bt >= 0 && bt < 32) slab[g.ob[DEC2] + bt] = bDec2;
+  };
+  auto write_dec0 = [&]() {
+    put16(g.ow[DEC0], gd, 16 * wave, 128, 0, gd, aDec0);
+    if (bt >= 0 && bt < 128) slab[g.ob[DEC0] + bt] = bDec0;
+  };
+  auto write_heads = [&]() {
+    // rows < g belong to to_mean, rows g..2g-1 to to_logvar
+    const int col = 16 * (wave & 3) + j;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = 16 * (wave >> 2) + 4 * q + e;
+      if (row < gd) slab[g.ow[MEAN] + (long)row * 64 + col] = aHead[e];
+      else if (row < 2 * gd) slab[g.ow[LOGVAR] + (long)(row - gd) * 64 + col] = aHead[e];
+    }
+    if (bt >= 0 && bt < gd) slab[g.ob[MEAN] + bt] = bHead;
+    else if (bt >= 0 && bt < 2 * gd) slab[g.ob[LOGVAR] + bt - gd] = bHead;
+  };
+  auto write_rho2 = [&]() {
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) put16(g.ow[RHO2], 128, 16 * rb, 64, 16 * wave, 128, aRho2[rb]);
+    if (bt >= 0 && bt < 64) slab[g.ob[RHO2] + bt] = bRho2;
+  };
+  auto write_rho0 = [&]() {
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) put16(g.ow[RHO0], 32, 16 * wave, 128, 16 * cb, 32, aRho0[cb]);
+    if (bt >= 0 && bt < 128) slab[g.ob[RHO0] + bt] = bRho0;
+  };
+  auto write_phi2 = [&]() {
+    if (wave < 2) put16(g.ow[PHI2], 16, 16 * wave, 32, 0, 16, aPhi2);
+    if (bt >= 0 && bt < 32) slab[g.ob[PHI2] + bt] = bPhi2;
+  };
+  auto write_phi0 = [&]() {
+    if (tid < 16) slab[g.ow[PHI0] + 2 * tid] = gPhi0;
+    else if (tid < 32) slab[g.ow[PHI0] + 2 * (tid - 16) + 1] = gPhi0;
+    else if (tid < 48) slab[g.ob[PHI0] + tid - 32] = gPhi0;
+  };
+  auto write_func2 = [&]() {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) put16(g.ow[FUNC2], 128, 16 * rb, 32, 16 * wave, 128, dW2a[rb]);
+  };
+
+  int tile = blockIdx.x;
+  do {
+    const int row0 = tile * ST_ROWS;
+    const bool first = SINGLE || tile == (int)blockIdx.x;
+    const int nlanes = min(ST_ROWS, g.B - row0);
+    const int ncars = nlanes * g.N;                    // cars of this tile: rows car_base .. car_base + ncars - 1
+    const long car_base = (long)row0 * g.N;
+    const int ntiles = (ncars + CAR_TILE - 1) / CAR_TILE;
+    if (!first) {                                      // the previous tile's images are dead (barrier at loop end)
+      car0 = request_cars16(row0);
+      commit_cars16(car0);
+      lds_barrier();
+    }
+    // the tile's reparameterisation noise: one element of [16][32] per thread (column c: mean part c < g, logvar part)
+    float eps_t = 0.f;
+    {
+      const int rr = tid >> 5, c = tid & 31;
+      const int jj = c < gd ? c : c - gd;
+      if (c < 2 * gd && row0 + rr < g.B) eps_t = g.eps[(long)(row0 + rr) * gd + jj];
+    }
+    HHRL_STAMP(3, 2);
+    // ================================================================= per-lane forward
+    // ---- phi.0 + ReLU summed over each lane's cars
+    if (tid < 256) {
+      const int rr = tid >> 4, k = tid & 15;
+      const float wa = bs[FB_PHI0 + 2 * k], wb = bs[FB_PHI0 + 2 * k + 1], bb = bs[FB_PHI0 + 32 + k];
+      float s = 0.f;
+      if (rr < nlanes) {
+        const float* x = staged ? Icars + rr * g.N * 2 : g.data + (car_base + (long)rr * g.N) * 2;
+        for (int n = 0; n < g.N; ++n) s += fmaxf(wa * x[2 * n] + wb * x[2 * n + 1] + bb, 0.f);
+      }
+      Ih1[rr * 33 + k] = s;
+    }
+    lds_barrier();
+    HHRL_STAMP(3, 22);
+    // ---- phi.2 on the summed hidden: pooled = W2 h1s + N b2 (two blocks)
+    if (wave < 2) {
+      const f32x4 c = wave_mma16<16, 33, 1, 1, 17>(Ih1, ovl + LW_PHI2 + 16 * wave * 17, lane, (float)g.N * bs[LB_PHI2 + 16 * wave + j]);
+      store_block16<33>(Ipool, 0, 16 * wave, c, lane);
+    }
+    lds_barrier();
+    HHRL_STAMP(3, 23);
+    // ---- rho.0 (32 -> 128, ReLU): block `wave`
+    {
+      f32x4 c = wave_mma16<32, 33, 1, 1, 33>(Ipool, ovl + LW_RHO0 + 16 * wave * 33, lane, bs[LB_RHO0 + 16 * wave + j]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) c[e] = fmaxf(c[e], 0.f);
+      store_block16<129>(Ir1, 0, 16 * wave, c, lane);
+    }
+    lds_barrier();
+    HHRL_STAMP(3, 24);
+    // ---- rho.2 (128 -> 64): four blocks on waves 0..3; meanwhile the last 128 threads form p and q (first tile)
+    if (wave < 4) {
+      const f32x4 c = wave_mma16<128, 129, 1, 1, 129>(Ir1, ovl + LW_RHO2 + 16 * wave * 129, lane, bs[LB_RHO2 + 16 * wave + j]);
+      store_block16<65>(Ir2, 0, 16 * wave, c, lane);
+    }
+    lds_barrier();
+    HHRL_STAMP(3, 25);
+    // ---- heads (64 -> 2g; columns >= 2g come out as zero): two blocks
+    if (wave < 2) {
+      const f32x4 c = wave_mma16<64, 65, 1, 1, 65>(Ir2, ovl + LW_HEAD + 16 * wave * 65, lane, bs[LB_HEAD + 16 * wave + j]);
+      store_block16<33>(Iml, 0, 16 * wave, c, lane);
+    }
+    lds_barrier();
+    HHRL_STAMP(3, 26);
+    // ---- reparameterisation z = mean + eps * exp(logvar / 2), zero-padded to 16 columns
+    {
+      const int rr = tid >> 5, c = tid & 31;
+      if (c < 16) {
+        float zv = 0.f;
+        if (c < gd && row0 + rr < g.B) zv = Iml[rr * 33 + c] + eps_t * expf(0.5f * Iml[rr * 33 + gd + c]);
+        Iz[rr * 17 + c] = zv;
+      }
+    }
+    lds_barrier();
+    HHRL_STAMP(3, 27);
+    // ---- decoder.0 (g -> 128, ReLU): block `wave`
+    {
+      f32x4 c = wave_mma16<16, 17, 1, 1, 17>(Iz, ovl + LW_DEC0 + 16 * wave * 17, lane, bs[LB_DEC0 + 16 * wave + j]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) c[e] = fmaxf(c[e], 0.f);
+      store_block16<129>(Id1, 0, 16 * wave, c, lane);
+    }
+    lds_barrier();
+    HHRL_STAMP(3, 28);
+    // ---- decoder.2 (128 -> 32): two blocks
+    if (wave < 2) {
+      const f32x4 c = wave_mma16<128, 129, 1, 1, 129>(Id1, ovl + LW_DEC2 + 16 * wave * 129, lane, bs[LB_DEC2 + 16 * wave + j]);
+      store_block16<33>(Id2, 0, 16 * wave, c, lane);
+    }
+    lds_barrier();
+    HHRL_STAMP(3, 3);
+    // ---- U = d2 A^T + q for the tile's cars: block `wave`, into the region the weight images leave
+    //      (no phase below reads them before they are staged again)
+    {
+      f32x4 c0, c1 = zero4;
+      const float qv = bs[FB_Q + 16 * wave + j];
+      c0 = f32x4{qv, qv, qv, qv};
+      const float* ap = Id2 + j * 33 + q;
+#pragma unroll
+      for (int s = 0; s < 8; s += 2) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s], w0u[s], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s + 4], w0u[s + 1], c1, 0, 0, 0);
+      }
+      store_block16<129>(Iu, 0, 16 * wave, c0 + c1, lane);
+    }
+    lds_barrier();
+    HHRL_STAMP(3, 4);
+
+    // ================================================================= the tile's cars
+    float4 S4 = make_float4(0.f, 0.f, 0.f, 0.f);       // S[lane tid / 32][columns 4 (tid % 32) ..]: df1 summed over the lane's cars
+    float p_t[8];
+#pragma unroll
+    for (int blk = 0; blk < 8; ++blk) p_t[blk] = bs[FB_P + 16 * blk + j];
+    for (int c_lo = 0; c_lo < ntiles; c_lo += ST_WAVES) {
+      const int nw = min(ST_WAVES, ntiles - c_lo);      // waves with a car tile in this round
+      const int ct = c_lo + wave;
+      const bool active = wave < nw;                    // wave-uniform
+      float loc_i[4], ind[4];
+      float in_v = 0.f;
+      int in_b = -1;
+      unsigned relu0 = 0u;                               // bit 4 blk + e: func.0's output (block blk, row 4 q + e) is positive
+      if (active) {
+        f32x4 f1[8];
+        // ---- inputs.  Lane j (all four groups q) holds car j of the tile; for the four rows 4 q + e of the
+        //      accumulator layout a lane also holds their loc and column 16 blk + j of their traffic lane's U row.
+        const int crow = ct * CAR_TILE + j;             // car within the lane tile
+        const bool valid = crow < ncars;
+        float2 lv = make_float2(0.f, 0.f);
+        if (valid) lv = staged ? *reinterpret_cast<const float2*>(Icars + 2 * crow)
+                               : *reinterpret_cast<const float2*>(g.data + 2 * (car_base + crow));
+        in_b = valid ? (int)((unsigned)crow / (unsigned)g.N) : -1;     // traffic lane within the tile, 0..15
+        int b_i[4], b_k[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          b_i[e] = __shfl(in_b, 4 * q + e, 64);
+          b_k[e] = __shfl(in_b, 4 * e + q, 64);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float* up = Iu + max(b_i[e], 0) * 129 + j;
+#pragma unroll
+          for (int blk = 0; blk < 8; ++blk) f1[blk][e] = up[16 * blk];
+        }
+        const int b_first = __builtin_amdgcn_readfirstlane(in_b);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ind[e] = (b_k[e] >= 0 && b_k[e] - b_first == j) ? 1.f : 0.f;
+        in_v = lv.y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) loc_i[e] = __shfl(lv.x, 4 * q + e, 64);
+        // ---- forward: func.0 = ReLU(U[lane] + loc * p)
+#pragma unroll
+        for (int blk = 0; blk < 8; ++blk) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            f1[blk][e] = fmaxf(fmaf(loc_i[e], p_t[blk], f1[blk][e]), 0.f);
+            relu0 |= (f1[blk][e] > 0.f ? 1u : 0u) << (4 * blk + e);
+          }
+          store_block16<129>(f1i, 0, 16 * blk, f1[blk], lane);
+        }
+        wave_sync();
+        HHRL_STAMP(3, 10);
+    // ---- forward: func.2 (128 -> 32, ReLU)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          f32x4 c = wave_mma16<128, 129, 1, 1, 129>(f1i, W2s + 16 * t * 129, lane, b2s[16 * t + j]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) c[e] = fmaxf(c[e], 0.f);
+          store_block16<33>(f2i, 0, 16 * t, c, lane);
+        }
+        wave_sync();
+        HHRL_STAMP(3, 11);
+    // ---- forward: func.4 (32 -> 1, sigmoid), squared error and its gradient per car
+        {
+          float s = 0.f;
+#pragma unroll
+          for (int n = 0; n < 8; ++n) s += w4s[8 * q + n] * f2i[j * 33 + 8 * q + n];
+          s += __shfl_xor(s, 16, 64);
+          s += __shfl_xor(s, 32, 64);
+          s += b4s[0];
+          const float out = 1.f / (1.f + expf(-s));
+          const float d = out - in_v;
+          float dp = 0.f;
+          if (in_b >= 0) {
+            if (q == 0) lossacc += g.recon_scale * d * d;
+            dp = 2.f * g.recon_scale * d * out * (1.f - out);
+          }
+          if (q == 0) {
+            dpre[j] = dp;
+            b4acc += dp;
+          }
+        }
+        wave_sync();
+        HHRL_STAMP(3, 12);
+    // ---- backward func.4 / ReLU of func.2: dW4, db2 and df2 (in place over the f2 image); lane: feature r32, cars 8 h32 ..
+        {
+          const float w4n = w4s[r32];
+#pragma unroll
+          for (int rr = 8 * h32; rr < 8 * h32 + 8; ++rr) {
+            const float fv = f2i[rr * 33 + r32];
+            const float dp = dpre[rr];
+            w4acc += dp * fv;
+            const float df = fv > 0.f ? dp * w4n : 0.f;
+            db2acc += df;
+            f2i[rr * 33 + r32] = df;
+          }
+        }
+        wave_sync();
+      }
+      HHRL_STAMP(3, 13);
+    // ---- df1 before its ReLU mask: (df2 W2), from the wave's own images (under the barrier's wait)
+      f32x4 df1[8];
+      if (active) {
+#pragma unroll
+        for (int blk = 0; blk < 8; ++blk) df1[blk] = wave_mma16<32, 33, 1, 129, 1>(f2i, W2s + 16 * blk, lane, 0.f);
+      }
+      HHRL_STAMP(3, 14);
+      lds_barrier();
+      HHRL_STAMP(3, 15);
+      // ---- func.2's weight gradient across the waves: dW2[32][128] += sum over the round's tiles of df2^T f1;
+      //      this wave owns the blocks (rows 0..15 and 16..31) x (columns 16 wave ..)
+#pragma unroll
+      for (int u = 0; u < ST_WAVES; ++u) {
+        if (u >= nw) break;
+        const float* fu = ovl + FO_WAVE0 + u * CAR_WAVE_FLOATS;
+        const float* a0 = fu + CAR_F2 + q * 33 + j;         // A(i = feature, k = car): df2[car][feature]
+        const float* b0 = fu + CAR_F1 + q * 129 + 16 * wave + j;   // B(k = car, j): f1[car][column]
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float bv = b0[4 * s * 129];
+          dW2a[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[4 * s * 33], bv, dW2a[0], 0, 0, 0);
+          dW2a[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[4 * s * 33 + 16], bv, dW2a[1], 0, 0, 0);
+        }
+      }
+      HHRL_STAMP(3, 16);
+      lds_barrier();                                   // every wave is done with the f1 images
+      HHRL_STAMP(3, 17);
+      if (active) {
+        // ---- ReLU mask of func.0, its column sums (db0, and s weighted by loc), df1 over the f1 image
+#pragma unroll
+        for (int blk = 0; blk < 8; ++blk) {
+          float cs = 0.f, ss = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float dv = ((relu0 >> (4 * blk + e)) & 1u) ? df1[blk][e] : 0.f;
+            df1[blk][e] = dv;
+            cs += dv;
+            ss = fmaf(dv, loc_i[e], ss);
+          }
+          db0[blk] += cs;
+          sacc[blk] += ss;
+          store_block16<129>(f1i, 0, 16 * blk, df1[blk], lane);
+        }
+        wave_sync();
+        HHRL_STAMP(3, 18);
+    // ---- df1 summed per traffic lane within the car tile on the matrix core (0/1 indicator operand):
+        //      P[s][col], s = traffic lane - first lane of the car tile; left in the wave's image block, [R][128]
+        f32x4 P[8];
+#pragma unroll
+        for (int blk = 0; blk < 8; ++blk) P[blk] = zero4;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+#pragma unroll
+          for (int blk = 0; blk < 8; ++blk)
+            P[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(ind[st], f1i[(4 * st + q) * 129 + 16 * blk + j], P[blk], 0, 0, 0);
+        }
+        wave_sync();                                     // the image has been read
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (4 * q + e < g.R) {
+#pragma unroll
+            for (int blk = 0; blk < 8; ++blk) wl[(4 * q + e) * 128 + 16 * blk + j] = P[blk][e];
+          }
+        }
+      }
+      HHRL_STAMP(3, 19);
+      lds_barrier();
+      HHRL_STAMP(3, 20);
+      // ---- S += the round's tiles, in tile order: a thread owns one traffic lane and four columns
+      {
+        const int rr = tid >> 5, c4 = 4 * (tid & 31);
+        for (int u = 0; u < nw; ++u) {
+          const int s = rr - (int)((unsigned)((c_lo + u) * CAR_TILE) / (unsigned)g.N);
+          if (s >= 0 && s < g.R) {
+            const float4 e = *reinterpret_cast<const float4*>(ovl + FO_WAVE0 + u * CAR_WAVE_FLOATS + s * 128 + c4);
+            S4.x += e.x; S4.y += e.y; S4.z += e.z; S4.w += e.w;
+          }
+        }
+      }
+      lds_barrier();                                   // the image blocks are free for the next round
+    }
+    HHRL_STAMP(3, 5);
+    if (SINGLE) write_func2();
+    // ---- the weight images are requested again (they are in L2); S takes U's place meanwhile.  The thread index
+    //      goes through an opaque copy, so that the addresses are formed again here instead of being kept in
+    //      registers (or spilled) since the prologue.
+    int tid_b = tid;
+    asm volatile("" : "+v"(tid_b));
+    request_weights(tid_b);
+    float w0r[32];                                       // func.0's columns for d2 as the B operand of dd2 = S A (waves 0, 1)
+    if (wave < 2) {
+      const float* src = (g.params + g.ow[FUNC0]) + q * 64 + 16 * wave + j;
+#pragma unroll
+      for (int s2 = 0; s2 < 32; ++s2) w0r[s2] = src[s2 * 256];
+    }
+    {
+      float* p = Iu + (tid >> 5) * 129 + 4 * (tid & 31);
+      p[0] = S4.x; p[1] = S4.y; p[2] = S4.z; p[3] = S4.w;
+    }
+    lds_barrier();
+
+    HHRL_STAMP(3, 30);
+    // ================================================================= per-lane backward
+    // ---- func.0, the part shared by a lane's cars: dd2 = S A (waves 0, 1), dA[128][32] += S^T d2 (row block `wave`)
+    {
+      if (wave < 2) {
+        const float* ap = Iu + j * 129 + q;
+        f32x4 c0 = zero4, c1 = zero4;
+#pragma unroll
+        for (int s2 = 0; s2 < 32; s2 += 2) {
+          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s2], w0r[s2], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s2 + 4], w0r[s2 + 1], c1, 0, 0, 0);
+        }
+        store_block16<33>(Itmp, 0, 16 * wave, c0 + c1, lane);
+      }
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) aF0[cb] = wave_mma16<16, 1, 129, 33, 1>(Iu + 16 * wave, Id2 + 16 * cb, lane, aF0[cb]);
+    }
+    HHRL_STAMP(3, 31);
+    if (SINGLE) write_f0();
+    lds_barrier();
+    commit_weights(tid_b);                               // over S (consumed) and the car images
+    lds_barrier();
+    HHRL_STAMP(3, 6);
+    // ---- decoder.2 backward: dW[32][128] += dd2^T d1 (column block `wave`), db, dd1 = (dd2 W) o relu'(d1) in place
+    {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) aDec2[rb] = wave_mma16<16, 1, 33, 129, 1>(Itmp + 16 * rb, Id1 + 16 * wave, lane, aDec2[rb]);
+      const f32x4 d = wave_mma16<32, 33, 1, 129, 1>(Itmp, ovl + LW_DEC2 + 16 * wave, lane, 0.f);
+      wave_sync();
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float* p = Id1 + (4 * q + e) * 129 + 16 * wave + j;
+        *p = *p > 0.f ? d[e] : 0.f;
+      }
+      if (tid >= 256 && tid < 288) bDec2 += colsum16(Itmp, 33, tid - 256);
+    }
+    if (SINGLE) write_dec2();
+    lds_barrier();
+    HHRL_STAMP(3, 32);
+    // ---- decoder.0 backward: dW[128][g] += dd1^T z (row block `wave`), db, dz = dd1 W as four partial products (waves 0..3)
+    {
+      aDec0 = wave_mma16<16, 1, 129, 17, 1>(Id1 + 16 * wave, Iz, lane, aDec0);
+      if (wave < 4) {
+        const f32x4 c = wave_mma16<32, 129, 1, 17, 1>(Id1 + 32 * wave, ovl + LW_DEC0 + 32 * wave * 17, lane, 0.f);
+        store_block16<17>(ovl + FO_SPARE + wave * 16 * 17, 0, 0, c, lane);
+      }
+      if (tid >= 256 && tid < 384) bDec0 += colsum16(Id1, 129, tid - 256);
+    }
+    if (SINGLE) write_dec0();
+    lds_barrier();
+    HHRL_STAMP(3, 33);
+    // ---- latent gradient (KL + reparameterisation): dml = [dz + mean | dz*eps*0.5*std + 0.5*(exp(lv)-1) | 0...]
+    {
+      const int rr = tid >> 5, c = tid & 31;
+      float outv = 0.f;
+      if (c < 2 * gd && row0 + rr < g.B) {
+        const int jj = c < gd ? c : c - gd;
+        const float mean = Iml[rr * 33 + jj], lv = Iml[rr * 33 + gd + jj];
+        const float* dzp = ovl + FO_SPARE + rr * 17 + jj;
+        const float dz = (dzp[0] + dzp[16 * 17]) + (dzp[2 * 16 * 17] + dzp[3 * 16 * 17]);
+        if (c < gd) {
+          outv = dz + mean;
+          klacc += -0.5f * (1.f + lv - mean * mean - expf(lv));
+        } else {
+          outv = dz * eps_t * 0.5f * expf(0.5f * lv) + 0.5f * (expf(lv) - 1.f);
+        }
+      }
+      Idml[rr * 33 + c] = outv;
+    }
+    lds_barrier();
+    HHRL_STAMP(3, 34);
+    // ---- heads backward: dW[2g][64] += dml^T r2 (block (wave / 4, wave % 4)), db, dr2 = dml W (waves 0..3; replaces r2)
+    {
+      aHead = wave_mma16<16, 1, 33, 65, 1>(Idml + 16 * (wave >> 2), Ir2 + 16 * (wave & 3), lane, aHead);
+      f32x4 d = zero4;
+      if (wave < 4) d = wave_mma16<32, 33, 1, 65, 1>(Idml, ovl + LW_HEAD + 16 * wave, lane, 0.f);
+      if (tid >= 256 && tid < 288) bHead += colsum16(Idml, 33, tid - 256);
+      lds_barrier();
+      if (wave < 4) store_block16<65>(Ir2, 0, 16 * wave, d, lane);
+    }
+    if (SINGLE) write_heads();
+    lds_barrier();
+    HHRL_STAMP(3, 35);
+    // ---- rho.2 backward: dW[64][128] += dr2^T r1 (column block `wave`, four row blocks), db, dr1 = (dr2 W) o relu'(r1) in place
+    {
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) aRho2[rb] = wave_mma16<16, 1, 65, 129, 1>(Ir2 + 16 * rb, Ir1 + 16 * wave, lane, aRho2[rb]);
+      const f32x4 d = wave_mma16<64, 65, 1, 129, 1>(Ir2, ovl + LW_RHO2 + 16 * wave, lane, 0.f);
+      wave_sync();
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float* p = Ir1 + (4 * q + e) * 129 + 16 * wave + j;
+        *p = *p > 0.f ? d[e] : 0.f;
+      }
+      if (tid >= 256 && tid < 320) bRho2 += colsum16(Ir2, 65, tid - 256);
+    }
+    if (SINGLE) write_rho2();
+    lds_barrier();
+    HHRL_STAMP(3, 36);
+    // ---- rho.0 backward: dW[128][32] += dr1^T pooled (row block `wave`), db, dpooled = dr1 W (waves 0, 1) -> ml slot
+    {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) aRho0[cb] = wave_mma16<16, 1, 129, 33, 1>(Ir1 + 16 * wave, Ipool + 16 * cb, lane, aRho0[cb]);
+      if (wave < 2) {
+        const f32x4 c = wave_mma16<128, 129, 1, 33, 1>(Ir1, ovl + LW_RHO0 + 16 * wave, lane, 0.f);
+        store_block16<33>(Iml, 0, 16 * wave, c, lane);
+      }
+      if (tid >= 256 && tid < 384) bRho0 += colsum16(Ir1, 129, tid - 256);
+    }
+    if (SINGLE) write_rho0();
+    lds_barrier();
+    HHRL_STAMP(3, 37);
+    // ---- phi.2 backward on the summed hidden: dW[32][16] += dpooled^T h1s (waves 0, 1), db = N colsum(dpooled),
+    //      t = dpooled W_phi2 (wave 2): gradient at the hidden layer of every car of the lane, before its ReLU mask
+    {
+      if (wave < 2) {
+        aPhi2 = wave_mma16<16, 1, 33, 33, 1>(Iml + 16 * wave, Ih1, lane, aPhi2);
+      } else if (wave == 2) {
+        const f32x4 c = wave_mma16<32, 33, 1, 17, 1>(Iml, ovl + LW_PHI2, lane, 0.f);
+        store_block16<33>(Itmp, 0, 0, c, lane);
+      }
+      if (tid >= 256 && tid < 288) bPhi2 += (float)g.N * colsum16(Iml, 33, tid - 256);
+    }
+    if (SINGLE) write_phi2();
+    lds_barrier();
+    HHRL_STAMP(3, 38);
+    // ---- phi.0 backward: per (lane, hidden unit) walk the cars again and apply the ReLU mask
+    {
+      float* red = Ir2;       // [16][49] partial sums
+      if (tid < 256) {
+        const int rr = tid >> 4, k = tid & 15;
+        const float wa = bs[FB_PHI0 + 2 * k], wb = bs[FB_PHI0 + 2 * k + 1], bb = bs[FB_PHI0 + 32 + k];
+        float a0 = 0.f, a1 = 0.f, c = 0.f;
+        if (rr < nlanes) {
+          const float* x = staged ? Icars + rr * g.N * 2 : g.data + (car_base + (long)rr * g.N) * 2;
+          for (int n = 0; n < g.N; ++n) {
+            const float x0 = x[2 * n], x1 = x[2 * n + 1];
+            if (wa * x0 + wb * x1 + bb > 0.f) { a0 += x0; a1 += x1; c += 1.f; }
+          }
+        }
+        const float t = Itmp[rr * 33 + k];
+        red[rr * 49 + k] = t * a0;
+        red[rr * 49 + 16 + k] = t * a1;
+        red[rr * 49 + 32 + k] = t * c;
+      }
+      lds_barrier();
+      if (tid < 48) {
+        float s = 0.f;
+        for (int rr = 0; rr < 16; ++rr) s += red[rr * 49 + tid];
+        gPhi0 += s;
+      }
+    }
+    if (SINGLE) write_phi0();
+    lds_barrier();
+    HHRL_STAMP(3, 7);
+  } while (!SINGLE && (tile += gridDim.x) < g.tiles);
+
+  // ================================================================= the workgroup's slab
+  // W0[8 og + k][32 + jj] for the loc gradients at the very end, requested now
+  float w0x[8];
+  {
+    const int jj = tid & 31, og = tid >> 5;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w0x[k] = (g.params + g.ow[FUNC0])[(8 * og + k) * 64 + 32 + jj];
+  }
+  if (!SINGLE) {
+    write_f0();
+    write_dec2();
+    write_dec0();
+    write_heads();
+    write_rho2();
+    write_rho0();
+    write_phi2();
+    write_phi0();
+    write_func2();
+  }
+  // ---- the per-car layers' small sums: lane groups first, then the eight waves through LDS in a fixed order
+#pragma unroll
+  for (int blk = 0; blk < 8; ++blk) {
+    db0[blk] += __shfl_xor(db0[blk], 16, 64);
+    db0[blk] += __shfl_xor(db0[blk], 32, 64);
+    sacc[blk] += __shfl_xor(sacc[blk], 16, 64);
+    sacc[blk] += __shfl_xor(sacc[blk], 32, 64);
+  }
+  w4acc += __shfl_xor(w4acc, 32, 64);
+  db2acc += __shfl_xor(db2acc, 32, 64);
+  b4acc = wave_sum(b4acc);
+  lossacc = wave_sum(lossacc);
+  klacc = wave_sum(klacc);
+  constexpr int Q1 = 328;                               // db0[128] s[128] db2[32] w4[32] b4 loss kl
+  constexpr int B_B0 = 0, B_S = 128, B_B2 = 256, B_W4 = 288, B_B4 = 320, B_LOSS = 321, B_KL = 322;
+  float* cmb = ovl;                                      // every image in the shared region is dead
+  {
+    float* mine = cmb + wave * Q1;
+    if (q == 0) {
+#pragma unroll
+      for (int blk = 0; blk < 8; ++blk) {
+        mine[B_B0 + 16 * blk + j] = db0[blk];
+        mine[B_S + 16 * blk + j] = sacc[blk];
+      }
+    }
+    if (h32 == 0) {
+      mine[B_B2 + r32] = db2acc;
+      mine[B_W4 + r32] = w4acc;
+    }
+    if (lane == 0) {
+      mine[B_B4] = b4acc;
+      mine[B_LOSS] = lossacc;
+      mine[B_KL] = klacc;
+    }
+  }
+  lds_barrier();
+  auto all8 = [&](int i) {
+    return ((cmb[i] + cmb[Q1 + i]) + (cmb[2 * Q1 + i] + cmb[3 * Q1 + i])) +
+           ((cmb[4 * Q1 + i] + cmb[5 * Q1 + i]) + (cmb[6 * Q1 + i] + cmb[7 * Q1 + i]));
+  };
+  float* fin = cmb + ST_WAVES * Q1;                      // s[128] | db0[128] | partial products [16][64]
+  if (tid < 128) {
+    const float sv = all8(B_S + tid);
+    fin[tid] = sv;
+    slab[g.ow[FUNC0] + tid * 64 + 32] = sv;           // s[o] travels in the first position of row o that no sum uses
+  } else if (tid < 256) {
+    const float dv = all8(B_B0 + tid - 128);
+    fin[tid] = dv;
+    slab[g.ob[FUNC0] + tid - 128] = dv;
+  } else if (tid < 288) {
+    slab[g.ob[FUNC2] + tid - 256] = all8(B_B2 + tid - 256);
+  } else if (tid < 320) {
+    slab[g.ow[FUNC4] + tid - 288] = all8(B_W4 + tid - 288);
+  } else if (tid == 320) {
+    slab[g.ob[FUNC4]] = all8(B_B4);
+  } else if (tid == 321) {
+    g.loss_part[blockIdx.x] = all8(B_LOSS);
+  } else if (tid == 322) {
+    g.kl_part[blockIdx.x] = all8(B_KL);
+  }
+  lds_barrier();
+  // ---- loc embedding: dwloc[jj] = sum_o s[o] W0[o][32 + jj], dbloc[jj] = sum_o db0[o] W0[o][32 + jj]
+  //      (this workgroup's share; sixteen groups of eight o each, combined in a fixed order)
+  {
+    const int jj = tid & 31, og = tid >> 5;
+    float pw = 0.f, pb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      pw = fmaf(fin[8 * og + k], w0x[k], pw);
+      pb = fmaf(fin[128 + 8 * og + k], w0x[k], pb);
+    }
+    fin[256 + og * 64 + jj] = pw;
+    fin[256 + og * 64 + 32 + jj] = pb;
+  }
+  lds_barrier();
+  if (tid < 64) {
+    const float* pp = fin + 256 + tid;
+    float sum = 0.f;
+#pragma unroll
+    for (int og = 0; og < 16; og += 4) sum += (pp[og * 64] + pp[(og + 1) * 64]) + (pp[(og + 2) * 64] + pp[(og + 3) * 64]);
+    slab[(tid < 32 ? g.ow[LOC] + tid : g.ob[LOC] + tid - 32)] = sum;
+  }
+  HHRL_STAMP(3, 8);
+}
+
 struct Ws {
   float *u, *aux, *spart, *act, *wimg, *loss_part, *kl_part, *slab;
   long total;
@@ -1635,6 +2523,14 @@ static int grid_lane(int B) {
   return (int)(tiles < 1 ? 1 : tiles);
 }
 
+static int grid_step(int B) {
+  long tiles = (B + ST_ROWS - 1) / ST_ROWS;
+  if (tiles > 256) tiles = 256;
+  return (int)(tiles < 1 ? 1 : tiles);
+}
+
+// The one-launch form needs aux, the loss / KL partials and one slab per workgroup; the four-launch form
+// the rest as well.  One layout serves both, so that the same workspace works whichever form runs.
 static Ws carve(float* ws, int B, int N, int g, long n_flat) {
   Ws w;
   long off = 0;
@@ -1646,7 +2542,8 @@ static Ws carve(float* ws, int B, int N, int g, long n_flat) {
   w.wimg = take(LN_WIMG_FLOATS);
   w.loss_part = take(256);
   w.kl_part = take(256);
-  const int ns = grid_car((long)B * N) > grid_lane(B) ? grid_car((long)B * N) : grid_lane(B);
+  int ns = grid_car((long)B * N) > grid_lane(B) ? grid_car((long)B * N) : grid_lane(B);
+  if (grid_step(B) > ns) ns = grid_step(B);
   w.slab = take((long)ns * n_flat);
   w.total = off;
   return w;
@@ -1702,6 +2599,57 @@ static int vae_step_impl(float* params, float* grads, float* m, float* v, const 
   Ws w = carve(ws, B, N, g, n_flat);
   const long rows = (long)B * N;
   const int ncar = grid_car(rows), nlane = grid_lane(B);
+
+  // Form of the step, both ending in the slab reduction: one launch for forward, ELBO and backward while the
+  // grid covers the batch with one tile of 16 lanes per workgroup (up to 4096 lanes), the four-launch form
+  // beyond (its kernels amortise their prologues over many tiles per workgroup).  HHRL_VAE_STEP=1 / =4 force
+  // one form for comparisons.
+  static int step_form = -1;
+  if (step_form < 0) {
+    const char* e = getenv("HHRL_VAE_STEP");
+    step_form = e ? atoi(e) : 0;
+  }
+  if (step_form == 1 || (step_form != 4 && (B + ST_ROWS - 1) / ST_ROWS <= 256)) {
+    HHRL_REQUIRE(n_flat < (1L << 31), "vae_train_step: flat buffer of %ld floats exceeds the 32-bit offsets", n_flat);
+    HHRL_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(vae_step_kernel<true>), ST_LDS_FLOATS * 4, "vae_train_step"));
+    HHRL_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(vae_step_kernel<false>), ST_LDS_FLOATS * 4, "vae_train_step"));
+    StepArgs sa;
+    sa.data = data;
+    sa.eps = eps;
+    sa.params = params;
+    for (int l = 0; l < NLAYER; ++l) {
+      sa.ow[l] = (int)off.w[l];
+      sa.ob[l] = (int)off.b[l];
+    }
+    sa.total = (int)n_flat;
+    sa.aux = w.aux;
+    sa.slab = w.slab;
+    sa.loss_part = w.loss_part;
+    sa.kl_part = w.kl_part;
+    sa.B = B; sa.N = N; sa.g = g;
+    sa.tiles = (B + ST_ROWS - 1) / ST_ROWS;
+    sa.R = lanes_per_car_tile(N);
+    sa.recon_scale = recon_scale;
+    const int ngrid = grid_step(B);
+    {
+      // the algorithm's products of the whole step: forward, input gradients, weight gradients
+      const double macs = 12896.0 * N + 16384.0 + 256.0 * g;
+      ProfScope ps("vae_step_kernel", st, 6.0 * macs * B, 4.0 * B * (2.0 * N + g), true);
+      if (ngrid >= sa.tiles)
+        launch_timed(ps, vae_step_kernel<true>, dim3(ngrid), dim3(ST_NT), ST_LDS_FLOATS * 4, st, sa);
+      else
+        launch_timed(ps, vae_step_kernel<false>, dim3(ngrid), dim3(ST_NT), ST_LDS_FLOATS * 4, st, sa);
+      HHRL_TRY(launch_status("vae_step_kernel"));
+    }
+    {
+      ProfScope ps("vae_reduce_grads_kernel", st, 0.0, 4.0 * ((double)n_flat * ngrid + n_flat * (adam ? 7.0 : 1.0)), true);
+      launch_timed(ps, vae_reduce_grads_kernel, dim3(ceil_div(n_flat, 64)), dim3(256), 0, st, w.slab, n_flat, ngrid, ngrid,
+                   car_lo, car_hi, f0_lo, b0_off, w.aux + 128, (const float*)nullptr, 0L, 0L, 0L, 0L, grads, w.loss_part, w.kl_part,
+                   loss, adam ? params : nullptr, m, v, adam ? *adam : AdamK());
+      HHRL_TRY(launch_status("vae_reduce_grads_kernel"));
+    }
+    return HHRL_OK;
+  }
 
   // Threads per workgroup of the per-lane kernels: 512 (four waves that only help with the copies into LDS
   // and the element-wise phases) unless HHRL_LANE_THREADS=256 asks for the plain form (for comparisons).
@@ -1940,9 +2888,9 @@ int hhrl_vae_decode(const float* params, const long* offsets, long n_flat, const
 }
 
 #ifdef HHRL_STAMPS
-// diagnostic builds only: copies the recorded clocks (3 kernels x 64 stamps) to the host
+// diagnostic builds only: copies the recorded clocks (4 kernels x 64 stamps) to the host
 int hhrl_debug_stamps(long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hhrl::vf::g_stamps), sizeof(long long) * 3 * 64);
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hhrl::vf::g_stamps), sizeof(long long) * 4 * 64);
 }
 #endif
 

@@ -30,6 +30,17 @@ LBWD = ["start", "weights, activations, S in LDS", "func.0 lane part (dd2, dA)",
         "rho.0 bwd", "phi.2 bwd", "phi.0 bwd", "slab written"]
 
 
+# the one-launch step: (stamp number, what ended there), in the order the kernel passes them
+STEP = [(0, "start"), (1, "weights, W2, cars in LDS"), (2, "tile start"), (22, "phi.0"), (23, "phi.2"), (24, "rho.0"), (25, "rho.2"),
+        (26, "heads"), (27, "reparam"), (28, "dec.0"), (3, "dec.2"), (4, "U = d2 A^T + q"),
+        (10, "car: inputs, func.0"), (11, "car: func.2 fwd"), (12, "car: func.4 + err"), (13, "car: func.4 bwd"),
+        (14, "car: df2 W2"), (15, "car: barrier 1"), (16, "car: dW2 across waves"), (17, "car: barrier 2"),
+        (18, "car: mask, column sums, df1 image"), (19, "car: per-lane sums"), (20, "car: barrier 3"), (5, "car: S accumulated (+ later rounds)"),
+        (30, "weights requested, S in LDS"), (31, "func.0 lane part (dd2, dA)"), (6, "weights in LDS again"), (32, "dec.2 bwd"),
+        (33, "dec.0 bwd"), (34, "latent"), (35, "heads bwd"), (36, "rho.2 bwd"), (37, "rho.0 bwd"), (38, "phi.2 bwd"), (7, "phi.0 bwd"),
+        (8, "slab, small sums, loc gradients")]
+
+
 def main():
     B, N, g = (int(a) for a in sys.argv[1:4]) if len(sys.argv) >= 4 else (4096, 7, 4)
     enc = Encoder(2, g, device="cuda:0", seed=1)
@@ -39,10 +50,19 @@ def main():
         enc.learn(x, sync=False)
     torch.cuda.synchronize()
     lib = _lib.load()
-    buf = (ctypes.c_longlong * (3 * 64))()
+    buf = (ctypes.c_longlong * (4 * 64))()
     lib.hhrl_debug_stamps.restype = ctypes.c_int
     assert lib.hhrl_debug_stamps(buf) == 0
-    st = np.array(buf[:]).reshape(3, 64)
+    st = np.array(buf[:]).reshape(4, 64)
+    if st[3, 0] != 0:                       # the one-launch form ran
+        span = st[3, 8] - st[3, 0]
+        print("vae_step: %d clocks" % span)
+        prev = st[3, 0]
+        for idx, label in STEP[1:]:
+            d = st[3, idx] - prev
+            prev = st[3, idx]
+            print("  %-40s %8d  %5.1f%%" % (label, d, 100.0 * d / span))
+        return
     for k, (name, labels) in enumerate((("vae_car_fwd_bwd", CAR), ("vae_lane_forward", LFWD), ("vae_lane_backward", LBWD))):
         t = st[k, :len(labels)]
         span = t[-1] - t[0]
