@@ -2504,6 +2504,83 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
   HHRL_STAMP(3, 8);
 }
 
+// The same reduction for the one-launch step, where every column is summed over the same n slabs: 64
+// consecutive parameters per workgroup, read 16 bytes per thread.  Thread (rq = tid / 16, c4 = tid % 16) adds
+// rows rq, rq + 16, ... of columns 4 c4 .. 4 c4 + 3 in row order (four running sums of every fourth of its rows
+// keep several loads in flight), LDS combines the sixteen row phases in a fixed order: the same inputs give
+// the same bits.  Requires total % 4 == 0, a 16-byte aligned slab and f0_lo % 64 == 0 (a row of func.0's matrix
+// is then exactly one workgroup's block, whose column 32 carries s[o]).
+__global__ __launch_bounds__(256) void vae_reduce_slabs_kernel(const float* __restrict__ slab, long total, int n, long f0_lo, long b0_off,
+                                                               const float* __restrict__ locsave, float* grads,
+                                                               const float* __restrict__ loss_part, const float* __restrict__ kl_part,
+                                                               float* loss, float* params, float* m, float* v, AdamK k) {
+  __shared__ float part[16][68];
+  __shared__ float dsum[4];
+  const int tid = threadIdx.x, c4 = tid & 15, rq = tid >> 4;
+  const long i0 = (long)blockIdx.x * 64;
+  const long e0 = i0 - f0_lo;
+  const bool f0_block = e0 >= 0 && e0 < 8192;             // a row of func.0's matrix (block-uniform)
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+  if (i0 + 4 * c4 < total) {
+    const float* col = slab + i0 + 4 * c4;
+    auto add = [](float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+    int r = rq;
+    for (; r + 48 < n; r += 64) {
+      const float4 v0 = *reinterpret_cast<const float4*>(col + (long)r * total);
+      const float4 v1 = *reinterpret_cast<const float4*>(col + (long)(r + 16) * total);
+      const float4 v2 = *reinterpret_cast<const float4*>(col + (long)(r + 32) * total);
+      const float4 v3 = *reinterpret_cast<const float4*>(col + (long)(r + 48) * total);
+      add(a0, v0); add(a1, v1); add(a2, v2); add(a3, v3);
+    }
+    for (; r < n; r += 16) add(a0, *reinterpret_cast<const float4*>(col + (long)r * total));
+  }
+  {
+    float* p = &part[rq][4 * c4];
+    p[0] = (a0.x + a1.x) + (a2.x + a3.x);
+    p[1] = (a0.y + a1.y) + (a2.y + a3.y);
+    p[2] = (a0.z + a1.z) + (a2.z + a3.z);
+    p[3] = (a0.w + a1.w) + (a2.w + a3.w);
+  }
+  // db0[o] of this row of func.0's matrix, summed over the slabs: rows tid, tid + 256, ...; waves then in a fixed order
+  if (f0_block) {
+    const long o = e0 >> 6;
+    float d = 0.f;
+    for (int r = tid; r < n; r += 256) d += slab[(long)r * total + b0_off + o];
+    d = wave_sum(d);
+    if ((tid & 63) == 0) dsum[tid >> 6] = d;
+  }
+  __syncthreads();
+  if (tid < 64 && i0 + tid < total) {
+    const long i = i0 + tid;
+    float s = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 16; rr += 4) s += (part[rr][tid] + part[rr + 1][tid]) + (part[rr + 2][tid] + part[rr + 3][tid]);
+    float gi = s;
+    if (f0_block && tid >= 32) {                           // column 32 + j: s[o] wloc[j] + db0[o] bloc[j]
+      float s32 = 0.f;
+#pragma unroll
+      for (int rr = 0; rr < 16; rr += 4) s32 += (part[rr][32] + part[rr + 1][32]) + (part[rr + 2][32] + part[rr + 3][32]);
+      const float di = (dsum[0] + dsum[1]) + (dsum[2] + dsum[3]);
+      const int jj = tid - 32;
+      gi = s32 * locsave[jj] + di * locsave[32 + jj];
+    }
+    grads[i] = gi;
+    if (params != nullptr) {                               // fused optimizer step (single device)
+      float pi = params[i], mi = m[i], vi = v[i];
+      adam_one(pi, gi, mi, vi, k);
+      params[i] = pi;
+      m[i] = mi;
+      v[i] = vi;
+    }
+  }
+  if (blockIdx.x == 0 && tid >= 64 && tid < 128) {
+    float t = 0.f;
+    for (int kk = tid - 64; kk < n; kk += 64) t += loss_part[kk] + kl_part[kk];
+    t = wave_sum(t);
+    if (tid == 64) *loss = t;
+  }
+}
+
 struct Ws {
   float *u, *aux, *spart, *act, *wimg, *loss_part, *kl_part, *slab;
   long total;
@@ -2642,11 +2719,17 @@ static int vae_step_impl(float* params, float* grads, float* m, float* v, const 
       HHRL_TRY(launch_status("vae_step_kernel"));
     }
     {
-      ProfScope ps("vae_reduce_grads_kernel", st, 0.0, 4.0 * ((double)n_flat * ngrid + n_flat * (adam ? 7.0 : 1.0)), true);
-      launch_timed(ps, vae_reduce_grads_kernel, dim3(ceil_div(n_flat, 64)), dim3(256), 0, st, w.slab, n_flat, ngrid, ngrid,
-                   car_lo, car_hi, f0_lo, b0_off, w.aux + 128, (const float*)nullptr, 0L, 0L, 0L, 0L, grads, w.loss_part, w.kl_part,
-                   loss, adam ? params : nullptr, m, v, adam ? *adam : AdamK());
-      HHRL_TRY(launch_status("vae_reduce_grads_kernel"));
+      const bool vec = n_flat % 4 == 0 && reinterpret_cast<uintptr_t>(w.slab) % 16 == 0 && f0_lo % 64 == 0;
+      ProfScope ps(vec ? "vae_reduce_slabs_kernel" : "vae_reduce_grads_kernel", st, 0.0,
+                   4.0 * ((double)n_flat * ngrid + n_flat * (adam ? 7.0 : 1.0)), true);
+      if (vec)
+        launch_timed(ps, vae_reduce_slabs_kernel, dim3(ceil_div(n_flat, 64)), dim3(256), 0, st, w.slab, n_flat, ngrid, f0_lo, b0_off,
+                     w.aux + 128, grads, w.loss_part, w.kl_part, loss, adam ? params : nullptr, m, v, adam ? *adam : AdamK());
+      else
+        launch_timed(ps, vae_reduce_grads_kernel, dim3(ceil_div(n_flat, 64)), dim3(256), 0, st, w.slab, n_flat, ngrid, ngrid,
+                     car_lo, car_hi, f0_lo, b0_off, w.aux + 128, (const float*)nullptr, 0L, 0L, 0L, 0L, grads, w.loss_part, w.kl_part,
+                     loss, adam ? params : nullptr, m, v, adam ? *adam : AdamK());
+      HHRL_TRY(launch_status("vae_reduce_slabs_kernel"));
     }
     return HHRL_OK;
   }
