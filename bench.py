@@ -471,7 +471,8 @@ def main() -> None:
         lane_macs = 512 + 4096 + 8192 + 128.0 * g + 128.0 * g + 4096
         executed = {"vae_car_fwd_bwd_kernel": 2.0 * (3 * 4096 + 16 * 128) * B * N,
                     "vae_lane_forward_kernel": 2.0 * (lane_macs + 4096) * B,
-                    "vae_lane_backward_kernel": 2.0 * (2 * lane_macs + 2 * 4096) * B}.get(dom_name)
+                    "vae_lane_backward_kernel": 2.0 * (2 * lane_macs + 2 * 4096) * B,
+                    "vae_step_kernel": vae_executed_flops_per_lane(N, g) * B}.get(dom_name)
         if mfma_bound and executed is not None:
             ex = executed * dom["launches"] / (dom["ms"] * 1e-3) / 1e12
             roof["executed"] = ex

@@ -12,6 +12,8 @@ kept under profiles/:
                                     SQ_INSTS_VALU_MFMA_MOPS_F32 (executed matrix FLOPs / 512), GRBM_GUI_ACTIVE
 
 usage: python tools/summarize_prof.py <tag>        (on the CPU box, after the GPU call has merged its files)
+       python tools/summarize_prof.py --td3 <tag>  (tools/profile_td3.sh <tag>: <tag>_td3_<config>_kernel_stats.csv,
+                                                    each with the traced run's wall time per update in a comment line)
 """
 import csv
 import glob
@@ -21,7 +23,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = ("vae_lane_forward_kernel", "vae_car_fwd_bwd_kernel", "vae_lane_backward_kernel", "vae_reduce_grads_kernel")
+KERNELS = ("vae_step_kernel", "vae_reduce_slabs_kernel", "vae_lane_forward_kernel", "vae_car_fwd_bwd_kernel",
+           "vae_lane_backward_kernel", "vae_reduce_grads_kernel")
 
 
 def one(pattern):
@@ -44,7 +47,24 @@ def counter_per_launch(path, counter):
     return {k: tot[k] / cnt[k] for k in tot}
 
 
+def td3(tag):
+    dst = os.path.join(ROOT, "profiles")
+    for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "prof_%s_td3_*" % tag))):
+        cfg = os.path.basename(d)[len("prof_%s_td3_" % tag):]
+        line = open(os.path.join(d, "line.json")).read().strip().splitlines()[-1]
+        out_path = os.path.join(dst, "%s_td3_%s_kernel_stats.csv" % (tag, cfg))
+        with open(one(d + "/trace/**/*_kernel_stats.csv"), newline="") as f, open(out_path, "w", newline="") as out:
+            out.write("# rocprofv3 --kernel-trace --stats -- python3 tools/td3_trace.py %s 200 ; %s\n" % (cfg.replace("_b", " "), line))
+            w = csv.writer(out)
+            for row in csv.reader(f):
+                row[0] = row[0][:160]
+                w.writerow(row)
+        print(out_path, line)
+
+
 def main():
+    if sys.argv[1] == "--td3":
+        return td3(sys.argv[2])
     tag = sys.argv[1]
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     dst = os.path.join(ROOT, "profiles")
