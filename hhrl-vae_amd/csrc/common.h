@@ -40,6 +40,13 @@ int ensure_dyn_lds(const void* fn, int bytes, const char* who);
 
 constexpr int kWave = 64;  // CDNA wavefront width
 
+// Workgroup barrier for hand-offs through LDS only: waits for this wave's LDS traffic, not for its global
+// loads and stores, so that requests issued before the barrier stay in flight across it (__syncthreads() would
+// wait for them: its fence covers global memory too).  Only for phases that exchange nothing through global memory.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

@@ -140,18 +140,19 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& g, int bx, int b
   // reduction range needs exact values: the last element of an odd chunk and the zero row after it are
   // written separately.
   const int nra = min(32, g.M - i0), ncb = min(32, g.N - j0);
-  for (int k0 = kbeg; k0 < kend; k0 += SKC) {
+  // The chunks are software-pipelined: the loads of chunk n+1 are issued after chunk n has been written to
+  // LDS and before its products, so one memory latency is exposed per wave instead of one per chunk.
+  float av[RPL], bv[RPL], a_tail = 0.f, b_tail = 0.f;
+  auto request = [&](int k0) {
     const int kc = min(SKC, kend - k0);
-    const int kc2 = (kc + 1) & ~1;
     const int np = kc >> 1;                             // full (k, k+1) pairs in the chunk
-    // Stage both operand chunks: every lane first issues all of its loads (one exposed memory latency
-    // per chunk), then writes them to LDS.  As[k][i] = A(i0+i, k0+k), Bs[k][j] = B(k0+k, j0+j).
-    float av[RPL], bv[RPL], a_tail = 0.f, b_tail = 0.f;
 #pragma unroll
     for (int i = 0; i < RPL; ++i) {
       av[i] = 0.f;
       bv[i] = 0.f;
     }
+    a_tail = 0.f;
+    b_tail = 0.f;
     if (g.a_kcontig) {
       if (kl < kc) {
         const int first = hf * RPL;                     // this lane's rows: first .. first + RPL - 1
@@ -196,6 +197,19 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& g, int bx, int b
       }
       if (kc & 1) b_tail = col[(long)(kc - 1) * g.b_sk];
     }
+  };
+  // the epilogue's bias is requested with the first chunk
+  float bias_v[1024 / NT];
+#pragma unroll
+  for (int u = 0; u < 1024 / NT; ++u) {
+    const int gj = j0 + ((u * NT + tid) & 31);
+    bias_v[u] = (g.bias && g.mode != 2 && gj < g.N) ? g.bias[gj] : 0.f;
+  }
+  if (kbeg < kend) request(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += SKC) {
+    const int kc = min(SKC, kend - k0);
+    const int kc2 = (kc + 1) & ~1;
+    // As[k][i] = A(i0+i, k0+k), Bs[k][j] = B(k0+k, j0+j)
     if (g.a_kcontig) {
 #pragma unroll
       for (int i = 0; i < RPL; ++i) As[kl][hf * RPL + i] = av[i];
@@ -215,6 +229,7 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& g, int bx, int b
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (k0 + SKC < kend) request(k0 + SKC);
     for (int k = 0; k < kc2; k += 2)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k + h][r], Bs[k + h][r], acc, 0, 0, 0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -237,7 +252,7 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& g, int bx, int b
     if (g.mode == 2) {
       unsafeAtomicAdd(c, v);
     } else {
-      if (g.bias) v += g.bias[gj];
+      if (g.bias) v += bias_v[u];
       if (g.mode == 1) v += *c;
       *c = act_apply(v, g.act);
     }

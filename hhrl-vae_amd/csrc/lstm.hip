@@ -111,6 +111,17 @@ __global__ __launch_bounds__(NT) void lstm_step_forward_kernel(StepFwdGroup grp,
   float* Wq = lds + 32 * ld;             // [32][ld]  rows (gate q, unit j) at image row 8*q + j: W_hh | W_ih
   float* part = Wq + 32 * ld;            // [4][32][33] partial gate tiles
   const bool has_h = g.h_prev != nullptr;
+  // what the gate epilogue reads from memory (biases, the cell state before the step) is requested now,
+  // so that its latency passes under the staging and the product instead of after the last barrier
+  const int e_rr = tid >> 3, e_j = tid & 7;
+  const int e_b = row0 + e_rr, e_u = u0 + e_j;
+  const bool e_on = wave < 4 && e_b < B && e_u < H;
+  float e_bias[4] = {0.f, 0.f, 0.f, 0.f}, e_cp = 0.f;
+  if (e_on) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) e_bias[q] = g.b_ih[q * H + e_u] + g.b_hh[q * H + e_u];
+    if (g.c_prev) e_cp = g.c_prev[(long)e_b * H + e_u];
+  }
   {
     // every global load is issued before the first LDS write
     const int hq = H >> 2;               // float4 per state / W_hh row (H % 32 == 0 on this path)
@@ -179,16 +190,16 @@ __global__ __launch_bounds__(NT) void lstm_step_forward_kernel(StepFwdGroup grp,
   }
   __syncthreads();
   if (wave < 4) {
-    const int rr = tid >> 3, j = tid & 7;
-    const int b = row0 + rr, u = u0 + j;
-    if (b < B && u < H) {
+    const int rr = e_rr, j = e_j;
+    const int b = e_b, u = e_u;
+    if (e_on) {
       float pre[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int col = 8 * q + j;
         pre[q] = (part[(0 * 32 + rr) * 33 + col] + part[(1 * 32 + rr) * 33 + col]) +
                  (part[(2 * 32 + rr) * 33 + col] + part[(3 * 32 + rr) * 33 + col]);
-        pre[q] += g.b_ih[q * H + u] + g.b_hh[q * H + u];
+        pre[q] += e_bias[q];
       }
       float* gr = g.gates + (long)b * 4 * H;
       const float gi = sigmoidf_(pre[0]);
@@ -196,7 +207,7 @@ __global__ __launch_bounds__(NT) void lstm_step_forward_kernel(StepFwdGroup grp,
       const float gg = tanhf(pre[2]);
       const float go = sigmoidf_(pre[3]);
       gr[u] = gi; gr[H + u] = gf; gr[2 * H + u] = gg; gr[3 * H + u] = go;
-      const float cp = g.c_prev ? g.c_prev[(long)b * H + u] : 0.f;
+      const float cp = e_cp;
       const float c = gf * cp + gi * gg;
       const float hv = go * tanhf(c);
       g.c_out[(long)b * H + u] = c;
@@ -284,6 +295,20 @@ __global__ __launch_bounds__(NT) void lstm_step_backward_kernel(StepBwdGroup grp
   float* Dg = lds;                        // [16][4H+4]  dgates_t rows
   float* Wt = Dg + 16 * lda;              // [4H][17]    W_hh[k][u0 + j]
   float* part = Wt + G4 * 17;             // [4][16][17]
+  // the cell epilogue's operands (gates and cell states of step t-1, the running cell gradient) are requested
+  // now: their latency passes under the staging and the product
+  const int e_rr = tid >> 4, e_j = tid & 15;
+  const int e_b = row0 + e_rr, e_u = u0 + e_j;
+  const bool e_on = wave < 4 && e_b < B && e_u < H;
+  float e_g[4] = {0.f, 0.f, 0.f, 0.f}, e_cpv = 0.f, e_dc = 0.f, e_cpp = 0.f;
+  if (e_on) {
+    const float* gr = g.gates_p + (long)e_b * G4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) e_g[q] = gr[q * H + e_u];
+    e_cpv = g.c_p[(long)e_b * H + e_u];
+    e_dc = g.dc[(long)e_b * H + e_u];
+    if (g.c_pp) e_cpp = g.c_pp[(long)e_b * H + e_u];
+  }
   {
     // 16-byte loads, 2048 / NT + 2048 / NT per thread for H = 128, all issued before the LDS writes
     const int a4 = 16 * H;                // float4 count of the dgates tile (16 rows x 4H)
@@ -330,16 +355,15 @@ __global__ __launch_bounds__(NT) void lstm_step_backward_kernel(StepBwdGroup grp
   }
   __syncthreads();
   if (wave < 4) {
-    const int rr = tid >> 4, j = tid & 15;
-    const int b = row0 + rr, u = u0 + j;
-    if (b < B && u < H) {
+    const int rr = e_rr, j = e_j;
+    const int b = e_b, u = e_u;
+    if (e_on) {
       const float dhv = (part[(0 * 16 + rr) * 17 + j] + part[(1 * 16 + rr) * 17 + j]) +
                         (part[(2 * 16 + rr) * 17 + j] + part[(3 * 16 + rr) * 17 + j]);
-      const float* gr = g.gates_p + (long)b * G4;
-      const float gi = gr[u], gf = gr[H + u], gg = gr[2 * H + u], go = gr[3 * H + u];
-      const float tc = tanhf(g.c_p[(long)b * H + u]);
-      const float dcv = g.dc[(long)b * H + u] + dhv * go * (1.f - tc * tc);
-      const float cp = g.c_pp ? g.c_pp[(long)b * H + u] : 0.f;
+      const float gi = e_g[0], gf = e_g[1], gg = e_g[2], go = e_g[3];
+      const float tc = tanhf(e_cpv);
+      const float dcv = e_dc + dhv * go * (1.f - tc * tc);
+      const float cp = e_cpp;
       float* dg = g.dgates_p + (long)b * G4;
       dg[u] = dcv * gg * gi * (1.f - gi);
       dg[H + u] = dcv * cp * gf * (1.f - gf);
@@ -381,6 +405,396 @@ __global__ __launch_bounds__(256) void colsum2_kernel(ColsumGroup grp, int ld, i
     unsafeAtomicAdd(&g.db1[col], s);
     if (g.db2) unsafeAtomicAdd(&g.db2[col], s);
   }
+}
+
+// =====================================================================================================
+// The whole recurrence of a window in ONE launch (H = 128, per-step observation at most 32 wide).
+//
+// A workgroup (eight waves) owns four batch rows of one module and all 512 gate columns, so the hidden state
+// never leaves the CU between time steps.  The products run on v_mfma_f32_4x4x1_f32, which computes sixteen
+// independent 4x4 outer products per instruction: operand A holds the same four batch rows for every block
+// (lane 4b+i = row i), operand B one gate column per lane, the result register e of lane l is
+// (row e, column of lane l).  A lane therefore keeps ITS gate column of [W_hh | W_ih] in registers for the whole
+// window (128 + OPAD values, loaded once), and a time step reads only the four rows [h_{t-1} | x_t] from LDS:
+// no weight traffic per step.  Wave w owns hidden units 16w..16w+15 with their four gates (lane = 16*gate +
+// unit), so the cell update needs a wave-local exchange only; one workgroup barrier per step publishes h_t.
+// Batch rows beyond the first four are taken in further passes of the same workgroup (weights stay in
+// registers); workgroups with blockIdx.y = 1 compute the single step of the reverse direction (zero state,
+// input x[T-1]) on the vector ALU.
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+// Diagnostic builds (-DHHRL_STAMPS): shader clock of workgroup (0,0,0), thread 0 at marked points of the
+// one-launch recurrence; hhrl_debug_lstm_stamps() copies them out.
+#ifdef HHRL_STAMPS
+__device__ long long g_lstm_stamps[2][64];
+__device__ int g_lstm_stamp_wg;     // first forward workgroup of the forward kernel's grid (the reverse ones come before it)
+#define LSTM_STAMP(k, i) do { if (blockIdx.x == (k == 0 ? g_lstm_stamp_wg : 0) && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_lstm_stamps[k][i] = clock64(); } while (0)
+#else
+#define LSTM_STAMP(k, i) do { } while (0)
+#endif
+constexpr int SQ_H = 128, SQ_G = 512, SQ_XG = 72;      // SQ_XG: row stride of the wave-local gate exchange
+
+struct SeqFwdInst {
+  const float* obs;                                   // [B][ldobs], step t at columns [t*o, (t+1)*o)
+  const float *w_ih, *w_hh, *b_ih, *b_hh;             // forward direction
+  const float *w_ih_r, *b_ih_r, *b_hh_r;              // reverse direction
+  float *x_tm, *gates, *cbuf, *hbuf, *cat, *gates_r, *c_r;
+  int ldobs, o;
+};
+struct SeqFwdGroup { SeqFwdInst in[kMaxInst]; };
+
+constexpr int SQ_SLAB = 512 * 33 + 64;                 // one 32-column slab of a [512][.] weight matrix, row stride 33 (+16 per gate)
+template <int OPAD>
+__global__ __launch_bounds__(512) void lstm_seq_forward_kernel(SeqFwdGroup grp, int B, int T, int chunks, int gx_r) {
+  constexpr int H = SQ_H, G = SQ_G, LD = H + 4;           // LD * 4 bytes is a multiple of 16
+  // dynamic LDS: the weight slab of the prologue, later (same memory) the window's observations [T][4][OPAD] of the four rows
+  extern __shared__ __attribute__((aligned(16))) float dyn[];
+  float* xall = dyn;
+  __shared__ __attribute__((aligned(16))) float hs[2][4][LD];     // h_{t-1} / h_t of the four rows
+  __shared__ float xg[8][4][SQ_XG];
+  const SeqFwdInst& g = grp.in[blockIdx.z];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int o = g.o;
+  const long BH = (long)B * H;
+
+  if ((int)blockIdx.x < gx_r) {
+    // ---- reverse direction: one step from the zero state on x[T-1]; thread = gate column.  These workgroups come
+    // first in dispatch order and are few (each takes several groups of rows): they are done within microseconds.
+    float (*pre_r)[G + 4] = reinterpret_cast<float (*)[G + 4]>(dyn + 4 * OPAD);
+    float wr[OPAD];
+#pragma unroll
+    for (int c = 0; c < OPAD; ++c) wr[c] = c < o ? g.w_ih_r[(long)tid * o + c] : 0.f;
+    const float bias = g.b_ih_r[tid] + g.b_hh_r[tid];
+    const int xr = tid / OPAD, xc = tid - xr * OPAD;
+    const int row = tid >> 7, unit = tid & 127;
+    for (int chunk = blockIdx.x; chunk < chunks; chunk += gx_r) {
+      const int r0 = chunk * 4;
+      if (tid < 4 * OPAD)
+        xall[xr * OPAD + xc] = (xc < o && r0 + xr < B) ? g.obs[(long)(r0 + xr) * g.ldobs + (long)(T - 1) * o + xc] : 0.f;
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float s = bias;
+#pragma unroll
+        for (int c = 0; c < OPAD; ++c) s += xall[i * OPAD + c] * wr[c];
+        pre_r[i][tid] = s;
+      }
+      __syncthreads();
+      if (r0 + row < B) {
+        const float gi = sigmoidf_(pre_r[row][unit]);
+        const float gf = sigmoidf_(pre_r[row][H + unit]);
+        const float gg = tanhf(pre_r[row][2 * H + unit]);
+        const float go = sigmoidf_(pre_r[row][3 * H + unit]);
+        float* gr = g.gates_r + (long)(r0 + row) * G;
+        gr[unit] = gi; gr[H + unit] = gf; gr[2 * H + unit] = gg; gr[3 * H + unit] = go;
+        const float c = gi * gg;                       // the cell state before the step is zero
+        g.c_r[(long)(r0 + row) * H + unit] = c;
+        g.cat[(long)(r0 + row) * 2 * H + H + unit] = go * tanhf(c);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  const int bx = blockIdx.x - gx_r, gx_f = gridDim.x - gx_r;
+
+  LSTM_STAMP(0, 0);
+  // ---- forward direction.  Matrix role: lane = (gate, unit of the wave); cell role: lane = (row, unit of the wave)
+  const int mg = lane >> 4, mu = 16 * wave + (lane & 15);
+  const int wrow = mg * H + mu;                            // this lane's row of W_ih / W_hh
+  float wh[H], wi[OPAD];
+  {
+    // A lane needs one whole ROW of the weight matrices.  Read row by row from memory that is 64 cache lines per
+    // instruction; instead the workgroup copies the matrices through LDS in slabs of 32 columns (coalesced: eight
+    // threads per 128-byte run) and every lane picks its row out of the slab.  The next slab's loads are issued
+    // before the current one is written.
+    const int lrow = wrow * 33 + 16 * mg;                  // 16 per gate: the four gates of a lane group fall on different banks
+    float4 nx[8];
+    auto request = [&](int slab) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int f = it * 512 + tid, row = f >> 3, c4 = f & 7;
+        nx[it] = *reinterpret_cast<const float4*>(g.w_hh + (long)row * H + 32 * slab + 4 * c4);
+      }
+    };
+    request(0);
+    // W_ih [512][o] is one contiguous block: element e -> (row e / o, column e % o), image row stride o | 1
+    const int so = o | 1;
+    for (int e = tid; e < G * o; e += 512) {
+      const int row = e / o, c = e - row * o;
+      dyn[row * so + c] = g.w_ih[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < OPAD; ++c) wi[c] = dyn[wrow * so + (c < o ? c : 0)];
+#pragma unroll
+    for (int c = 0; c < OPAD; ++c) wi[c] = c < o ? wi[c] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int slab = 0; slab < 4; ++slab) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int f = it * 512 + tid, row = f >> 3, c4 = f & 7;
+        float* p = dyn + row * 33 + 16 * (row >> 7) + 4 * c4;
+        p[0] = nx[it].x; p[1] = nx[it].y; p[2] = nx[it].z; p[3] = nx[it].w;
+      }
+      if (slab + 1 < 4) request(slab + 1);
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 32; ++k) wh[32 * slab + k] = dyn[lrow + k];
+      __syncthreads();
+    }
+  }
+  const float bias = g.b_ih[wrow] + g.b_hh[wrow];
+  const int crow = lane >> 4, cu = mu;                     // cell role
+  const int arow = lane & 3;                               // operand A: lane 4b+i carries batch row i
+
+  for (int chunk = bx; chunk < chunks; chunk += gx_f) {
+    const int r0 = chunk * 4;
+    const bool valid = r0 + crow < B;
+    // the window's observations of the four rows: into LDS once, and out again time-major (the weight-gradient
+    // products read them that way); nothing is loaded from memory inside the time loop
+    for (int e = tid; e < T * 4 * OPAD; e += 512) {
+      const int xc = e % OPAD, rt = e / OPAD, xr = rt & 3, t = rt >> 2;
+      const bool in = xc < o && r0 + xr < B;
+      const float v = in ? g.obs[(long)(r0 + xr) * g.ldobs + (long)t * o + xc] : 0.f;
+      xall[e] = v;
+      if (in) g.x_tm[((long)t * B + r0 + xr) * o + xc] = v;
+    }
+    if (valid) {                                           // the zero slot of the state buffers
+      g.hbuf[(long)(r0 + crow) * H + cu] = 0.f;
+      g.cbuf[(long)(r0 + crow) * H + cu] = 0.f;
+    }
+    float c = 0.f;
+    // Everything requested so far (weights, bias, observations) is waited for HERE: inside the loop the compiler
+    // would otherwise wait for "all memory traffic" at the first use, which there includes the previous step's stores.
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+    lds_barrier();
+    LSTM_STAMP(0, 1);
+    for (int t = 0; t < T; ++t) {
+      const int cur = t & 1;
+      f32x4s a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+      const float* hp = &hs[cur][arow][0];
+      const float* xp = xall + (t * 4 + arow) * OPAD;
+      constexpr int XQ = OPAD / 4;                         // 16-byte groups of the observation part
+      auto group = [&](int q) -> float4 {
+        return q < XQ ? *reinterpret_cast<const float4*>(xp + 4 * q) : *reinterpret_cast<const float4*>(hp + 4 * (q - XQ));
+      };
+      auto weight = [&](int k) -> float { return k < OPAD ? wi[k < OPAD ? k : 0] : wh[k < OPAD ? 0 : k - OPAD]; };
+      if (t == 0) {                                        // zero state: the observation part only
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+          const float4 v = group(q);
+          a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(v.x, wi[4 * q], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(v.y, wi[4 * q + 1], a1, 0, 0, 0);
+          a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(v.z, wi[4 * q + 2], a2, 0, 0, 0);
+          a3 = __builtin_amdgcn_mfma_f32_4x4x1f32(v.w, wi[4 * q + 3], a3, 0, 0, 0);
+        }
+      } else {
+        // Blocks of four groups (16 products = 128 matrix-pipe cycles): the LDS reads of block n+1 are issued
+        // before the products of block n, so that their latency passes under them.
+        constexpr int NB = (XQ + H / 4) / 4;
+        float4 va[4], vb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) va[i] = group(i);
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+          if (blk + 1 < NB) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vb[i] = group(4 * (blk + 1) + i);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int k = 16 * blk + 4 * i;
+            a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(va[i].x, weight(k), a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(va[i].y, weight(k + 1), a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(va[i].z, weight(k + 2), a2, 0, 0, 0);
+            a3 = __builtin_amdgcn_mfma_f32_4x4x1f32(va[i].w, weight(k + 3), a3, 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) va[i] = vb[i];
+        }
+      }
+      if (t == 1) LSTM_STAMP(0, 2);
+      if (t == 2) LSTM_STAMP(0, 6);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xg[wave][i][lane] = ((a0[i] + a1[i]) + (a2[i] + a3[i])) + bias;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const float* pr = &xg[wave][crow][lane & 15];
+      const float gi = sigmoidf_(pr[0]);
+      const float gf = sigmoidf_(pr[16]);
+      const float gg = tanhf(pr[32]);
+      const float go = sigmoidf_(pr[48]);
+      c = gf * c + gi * gg;
+      const float hv = go * tanhf(c);
+      if (t == 1) LSTM_STAMP(0, 3);
+      hs[cur ^ 1][crow][cu] = hv;
+      if (valid) {
+        const long rb = (long)t * B + r0 + crow;
+        float* gr = g.gates + rb * G;
+        gr[cu] = gi; gr[H + cu] = gf; gr[2 * H + cu] = gg; gr[3 * H + cu] = go;
+        g.cbuf[BH + rb * H + cu] = c;
+        g.hbuf[BH + rb * H + cu] = hv;
+        if (t == T - 1) g.cat[(long)(r0 + crow) * 2 * H + cu] = hv;
+      }
+      if (t == 1) LSTM_STAMP(0, 4);
+      lds_barrier();
+      if (t == 1) LSTM_STAMP(0, 5);
+      if (t == T - 1) LSTM_STAMP(0, 7);
+    }
+  }
+}
+
+// Back-propagation through the whole window in one launch, same ownership (four batch rows, all units).
+// Matrix role: wave w reduces gate w/2's 128 columns of dgates_t for the 64 units of half w%2 (lane = unit),
+// with its 128 values of W_hh in registers; the four partial results per (row, unit) are summed through LDS in
+// gate order.  Cell role: thread = (row, unit) keeps the running cell gradient in a register.
+struct SeqBwdInst {
+  const float *w_hh, *gates, *cbuf, *dcat, *gates_r, *c_r;
+  float *dgates, *dgates_r;
+};
+struct SeqBwdGroup { SeqBwdInst in[kMaxInst]; };
+
+__global__ __launch_bounds__(512) void lstm_seq_backward_kernel(SeqBwdGroup grp, int B, int T, int chunks) {
+  constexpr int H = SQ_H, G = SQ_G, LD = G + 4;
+  __shared__ __attribute__((aligned(16))) float dg[4][LD];
+  __shared__ float part[4][4][H + 1];
+  const SeqBwdInst& g = grp.in[blockIdx.z];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row = tid >> 7, unit = tid & 127;              // cell role
+  const long BH = (long)B * H;
+
+  if (blockIdx.y == 1) {
+    // ---- the reverse direction's single cell: hidden gradient from the fc layer, zero state before the step
+    for (int chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+      const int b = chunk * 4 + row;
+      if (b >= B) continue;
+      const float* gr = g.gates_r + (long)b * G;
+      const float gi = gr[unit], gg = gr[2 * H + unit], go = gr[3 * H + unit];
+      const float tc = tanhf(g.c_r[(long)b * H + unit]);
+      const float dhv = g.dcat[(long)b * 2 * H + H + unit];
+      const float dcv = dhv * go * (1.f - tc * tc);
+      float* d = g.dgates_r + (long)b * G;
+      d[unit] = dcv * gg * gi * (1.f - gi);
+      d[H + unit] = 0.f;
+      d[2 * H + unit] = dcv * gi * (1.f - gg * gg);
+      d[3 * H + unit] = dhv * tc * go * (1.f - go);
+    }
+    return;
+  }
+
+  LSTM_STAMP(1, 0);
+  const int ch = wave & 1, gq = wave >> 1;
+  float wq[H];
+#pragma unroll
+  for (int c = 0; c < H; ++c) wq[c] = g.w_hh[((long)gq * H + c) * H + 64 * ch + lane];
+  const int arow = lane & 3;
+
+  for (int chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+    const int b = chunk * 4 + row;
+    const bool valid = b < B;
+    float dc = 0.f;
+    // cell backward of step s with hidden gradient dhv; leaves dgates_s in LDS and in memory
+    auto cell = [&](int s, float dhv, float gi, float gf, float gg, float go, float cs, float cp) {
+      const float tc = tanhf(cs);
+      const float dcv = dc + dhv * go * (1.f - tc * tc);
+      const float d0 = dcv * gg * gi * (1.f - gi);
+      const float d1 = dcv * cp * gf * (1.f - gf);
+      const float d2 = dcv * gi * (1.f - gg * gg);
+      const float d3 = dhv * tc * go * (1.f - go);
+      dc = dcv * gf;
+      dg[row][unit] = valid ? d0 : 0.f;
+      dg[row][H + unit] = valid ? d1 : 0.f;
+      dg[row][2 * H + unit] = valid ? d2 : 0.f;
+      dg[row][3 * H + unit] = valid ? d3 : 0.f;
+      if (valid) {
+        float* d = g.dgates + ((long)s * B + b) * G;
+        d[unit] = d0; d[H + unit] = d1; d[2 * H + unit] = d2; d[3 * H + unit] = d3;
+      }
+    };
+    float n_g[4] = {0.f, 0.f, 0.f, 0.f}, n_c = 0.f, n_cp = 0.f;
+    auto fetch = [&](int s) {                              // operands of the cell backward of step s
+      if (!valid) return;
+      const float* gr = g.gates + ((long)s * B + b) * G;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) n_g[q] = gr[q * H + unit];
+      n_c = g.cbuf[BH + ((long)s * B + b) * H + unit];
+      n_cp = s > 0 ? g.cbuf[BH + ((long)(s - 1) * B + b) * H + unit] : 0.f;
+    };
+    fetch(T - 1);
+    cell(T - 1, valid ? g.dcat[(long)b * 2 * H + unit] : 0.f, n_g[0], n_g[1], n_g[2], n_g[3], n_c, n_cp);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): the weights; see the forward kernel
+    lds_barrier();
+    LSTM_STAMP(1, 1);
+    for (int t = T - 1; t >= 1; --t) {
+      fetch(t - 1);
+      f32x4s a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+      const float* ap = &dg[arow][gq * H];
+      {
+        // blocks of four 16-byte groups, the reads of block n+1 issued before the products of block n
+        float4 va[4], vb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) va[i] = *reinterpret_cast<const float4*>(ap + 4 * i);
+#pragma unroll
+        for (int blk = 0; blk < H / 16; ++blk) {
+          if (blk + 1 < H / 16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vb[i] = *reinterpret_cast<const float4*>(ap + 16 * (blk + 1) + 4 * i);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int k = 16 * blk + 4 * i;
+            a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(va[i].x, wq[k], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(va[i].y, wq[k + 1], a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(va[i].z, wq[k + 2], a2, 0, 0, 0);
+            a3 = __builtin_amdgcn_mfma_f32_4x4x1f32(va[i].w, wq[k + 3], a3, 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) va[i] = vb[i];
+        }
+      }
+      if (t == T - 2) LSTM_STAMP(1, 2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) part[gq][i][64 * ch + lane] = (a0[i] + a1[i]) + (a2[i] + a3[i]);
+      lds_barrier();
+      if (t == T - 2) LSTM_STAMP(1, 3);
+      const float dhv = (part[0][row][unit] + part[1][row][unit]) + (part[2][row][unit] + part[3][row][unit]);
+      cell(t - 1, dhv, n_g[0], n_g[1], n_g[2], n_g[3], n_c, n_cp);
+      if (t == T - 2) LSTM_STAMP(1, 4);
+      lds_barrier();
+      if (t == T - 1) LSTM_STAMP(1, 6);
+      if (t == T - 2) LSTM_STAMP(1, 5);
+      if (t == 1) LSTM_STAMP(1, 7);
+    }
+  }
+}
+
+// The one-launch recurrence serves H = 128 with observations up to 32 wide and 16-byte aligned W_hh rows;
+// HHRL_LSTM_SEQ=0 selects the per-step kernels instead (A/B timing).
+constexpr int kSeqMaxT = 64;       // the forward kernel keeps the window's observations of its rows in LDS: T * 4 * 32 floats at most
+static bool seq_fits(const hhrl_lstm_desc* d, int n, int H, int T) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("HHRL_LSTM_SEQ");
+    on = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  if (!on || H != SQ_H || T > kSeqMaxT) return false;
+  for (int i = 0; i < n; ++i) {
+    if (d[i].o > 32) return false;
+    if (reinterpret_cast<uintptr_t>(d[i].params[1]) & 15) return false;
+  }
+  return true;
+}
+static int seq_grid_x(int chunks, int n) {
+  int gx = 200 / n;                 // forward workgroups of all modules (plus the few reverse ones) within one round of the 256 CUs; further rows in passes of the same workgroup
+  if (gx < 1) gx = 1;
+  return chunks < gx ? chunks : gx;
 }
 
 static int set_step_attrs(int H) {
@@ -442,14 +856,38 @@ int hhrl_lstm_forward_group(const hhrl_lstm_desc* d, int n, int B, int T, int H,
     omax = d[i].o > omax ? d[i].o : omax;
     pg.in[i] = PrepInst{d[i].obs, w[i].x_tm, w[i].hbuf, w[i].cbuf, d[i].ldobs, d[i].o};
   }
-  {
+  const bool seq = seq_fits(d, n, H, T);
+  if (seq) {
+    // transposition, all T steps and the reverse step in one launch
+    SeqFwdGroup sg;
+    for (int i = 0; i < n; ++i) {
+      const float* const* p = d[i].params;
+      sg.in[i] = SeqFwdInst{d[i].obs, p[0], p[1], p[2], p[3], p[4], p[6], p[7], w[i].x_tm, w[i].gates, w[i].cbuf, w[i].hbuf,
+                            w[i].cat, w[i].gates_r, w[i].c_r, d[i].ldobs, d[i].o};
+    }
+    const int chunks = ceil_div(B, 4);
+    const int gx_f = seq_grid_x(chunks, n), gx_r = gx_f >= 4 ? gx_f / 4 : 1;
+    const dim3 grid(gx_r + gx_f, 1, n);
+    const size_t lds_fwd = 4 * (size_t)((T * 4 * 32 > SQ_SLAB ? T * 4 * 32 : SQ_SLAB));
+    HHRL_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(lstm_seq_forward_kernel<16>), (int)lds_fwd, "lstm"));
+    HHRL_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(lstm_seq_forward_kernel<32>), (int)lds_fwd, "lstm"));
+    ProfScope ps("lstm_seq_forward_kernel", st, 2.0 * B * G * ((double)T * (H + omax) + omax) * n,
+                 4.0 * n * ((double)B * T * (G + 2.0 * H + 2.0 * omax) + (double)G * (H + 2.0 * omax)));
+#ifdef HHRL_STAMPS
+    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_lstm_stamp_wg), &gx_r, sizeof(int), 0, hipMemcpyHostToDevice, st);
+#endif
+    if (omax <= 16) hipLaunchKernelGGL(lstm_seq_forward_kernel<16>, grid, dim3(512), lds_fwd, st, sg, B, T, chunks, gx_r);
+    else hipLaunchKernelGGL(lstm_seq_forward_kernel<32>, grid, dim3(512), lds_fwd, st, sg, B, T, chunks, gx_r);
+    HHRL_TRY(launch_status("lstm_seq_forward_kernel"));
+  }
+  if (!seq) {
     const long work = (long)B * T * omax > BH ? (long)B * T * omax : BH;
     ProfScope ps("lstm_prep_kernel", st, 0.0, 8.0 * B * T * omax * n);
     hipLaunchKernelGGL(lstm_prep_kernel, dim3(ceil_div(work, 256), 1, n), dim3(256), 0, st, pg, B, T, H);
     HHRL_TRY(launch_status("lstm_prep_kernel"));
   }
-  const bool fused = fused_steps_fit(d, n, H);
-  if (!fused) {
+  const bool fused = !seq && fused_steps_fit(d, n, H);
+  if (!fused && !seq) {
     for (int i = 0; i < n; ++i) {
       const float* const* p = d[i].params;
       const int o = d[i].o;
@@ -537,7 +975,7 @@ int hhrl_lstm_forward_group(const hhrl_lstm_desc* d, int n, int B, int T, int H,
 
 int hhrl_lstm_backward_group(const hhrl_lstm_desc* d, int n, int B, int T, int H, void* stream) {
   HHRL_TRY(check_group(d, n, B, T, H, true));
-  const bool fused = fused_steps_fit(d, n, H);
+  const bool fused = !seq_fits(d, n, H, T) && fused_steps_fit(d, n, H);
   if (fused) HHRL_TRY(set_step_attrs(H));
   hipStream_t st = as_stream(stream);
   const int G = 4 * H;
@@ -565,8 +1003,20 @@ int hhrl_lstm_backward_group(const hhrl_lstm_desc* d, int n, int B, int T, int H
     HHRL_TRY(gemm_group(dx, n, st));
     HHRL_TRY(gemm_group(dw, n, st));
   }
+  const bool seq = seq_fits(d, n, H, T);
+  if (seq) {
+    // every cell of the window, both directions, in one launch
+    SeqBwdGroup sg;
+    for (int i = 0; i < n; ++i)
+      sg.in[i] = SeqBwdInst{d[i].params[1], w[i].gates, w[i].cbuf, w[i].dcat, w[i].gates_r, w[i].c_r, w[i].dgates, w[i].dgates_r};
+    const int chunks = ceil_div(B, 4);
+    ProfScope ps("lstm_seq_backward_kernel", st, 2.0 * B * G * H * (double)(T - 1) * n,
+                 4.0 * n * ((double)B * T * (2.0 * G + 2.0 * H) + (double)G * H));
+    hipLaunchKernelGGL(lstm_seq_backward_kernel, dim3(seq_grid_x(chunks, n), 2, n), dim3(512), 0, st, sg, B, T, chunks);
+    HHRL_TRY(launch_status("lstm_seq_backward_kernel"));
+  }
   // cells whose hidden gradient comes from the fc layer: last forward step and the reverse step
-  {
+  if (!seq) {
     CellBwdGroup cg;
     for (int i = 0; i < n; ++i) {
       cg.in[2 * i] = CellBwdInst{w[i].gates + (long)(T - 1) * B * G, T > 1 ? w[i].cbuf + (long)(T - 1) * BH : nullptr,
@@ -578,7 +1028,7 @@ int hhrl_lstm_backward_group(const hhrl_lstm_desc* d, int n, int B, int T, int H
     HHRL_TRY(launch_status("lstm_cell_backward_kernel"));
   }
   // steps T-1 .. 1: dh_{t-1} = dgates_t W_hh fused with the cell backward of step t-1
-  for (int t = T - 1; t >= 1 && !fused; --t) {
+  for (int t = T - 1; t >= 1 && !fused && !seq; --t) {
     // generic hidden size: dh_{t-1} = dgates_t W_hh as a GEMM, then the cell backward of step t-1
     CellBwdGroup cg;
     for (int i = 0; i < n; ++i) {
@@ -626,6 +1076,12 @@ int hhrl_lstm_backward_group(const hhrl_lstm_desc* d, int n, int B, int T, int H
   }
   return HHRL_OK;
 }
+
+#ifdef HHRL_STAMPS
+int hhrl_debug_lstm_stamps(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lstm_stamps), sizeof(long long) * 2 * 64) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int hhrl_lstm_forward(const float* obs, int ldobs, const float* const* params, float* out, int ldo, float* ws, int B,
                       int T, int o, int H, void* stream) {

@@ -1616,13 +1616,6 @@ __global__ __launch_bounds__(256) void vae_reduce_grads_kernel(const float* __re
   }
 }
 
-// Workgroup barrier for hand-offs through LDS only: waits for this wave's LDS traffic, not for its global
-// loads, so that requests issued before the barrier stay in flight across it (__syncthreads() would wait for
-// them: its fence covers global memory too).  Only for phases that exchange nothing through global memory.
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 
 // ===================================================================== the whole step in one launch
 // One workgroup (eight waves) owns tiles of 16 traffic lanes TOGETHER WITH their cars and runs the whole

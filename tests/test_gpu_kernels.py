@@ -308,7 +308,11 @@ def test_td3_target_mse_equals_two_launches(env, B):
     scaled_close("loss", lb.cpu().numpy(), la.cpu().numpy(), rtol=1e-5)
 
 
-@pytest.mark.parametrize("B,T,o,H", [(9, 5, 7, 12), (64, 10, 13, 128), (64, 10, 25, 128), (3, 1, 4, 8), (130, 4, 5, 8)])
+@pytest.mark.parametrize("B,T,o,H", [(9, 5, 7, 12), (64, 10, 13, 128), (64, 10, 25, 128), (3, 1, 4, 8), (130, 4, 5, 8),
+                                     # H = 128 with o <= 32 runs the whole window in one launch (four batch rows per workgroup):
+                                     # a partial last group of rows, one step, more row groups than workgroups, the widest
+                                     # observation it takes, and the first width that goes back to the per-step kernels
+                                     (7, 10, 13, 128), (1, 1, 3, 128), (1101, 3, 32, 128), (64, 10, 33, 128)])
 def test_lstm_forward_backward(env, B, T, o, H):
     """hhrl_lstm_forward/backward against torch.nn.LSTM(bidirectional) + Linear,
     taking r_out[:, -1, :] as the reference does (algorithm.py:152-156)."""
@@ -341,7 +345,8 @@ def test_lstm_forward_backward(env, B, T, o, H):
 
 
 # ------------------------------------------------------------------ grouped / fused entry points
-@pytest.mark.parametrize("B,T,H,obs_dims", [(64, 10, 128, (13, 13, 25)), (33, 4, 32, (5, 29)), (7, 3, 8, (4, 6, 3))])
+@pytest.mark.parametrize("B,T,H,obs_dims", [(64, 10, 128, (13, 13, 25)), (33, 4, 32, (5, 29)), (7, 3, 8, (4, 6, 3)),
+                                            (130, 6, 128, (13, 32, 5)), (350, 2, 128, (1, 16, 17, 9, 9, 9, 9, 9, 9))])
 def test_lstm_group_matches_torch(env, B, T, H, obs_dims):
     """hhrl_lstm_forward_group / _backward_group: several LSTM modules with different observation
     widths in one call, each against torch.nn.LSTM + Linear."""
