@@ -431,6 +431,17 @@ __device__ int g_lstm_stamp_wg;     // first forward workgroup of the forward ke
 #else
 #define LSTM_STAMP(k, i) do { } while (0)
 #endif
+// Gate nonlinearities of the one-launch recurrence: the hardware exponential and reciprocal (about 1 ulp each)
+// instead of the library routines, whose 25-45 instructions per call made the cell update as long as the products.
+// sigmoid: relative error < 4e-7.  tanh: 1 - 2 / (e^{2x} + 1) has absolute error about 1e-7, which is a large
+// RELATIVE error for small arguments, so below 0.25 the odd Taylor polynomial through x^9 takes over (next term < 3e-9).
+__device__ __forceinline__ float sq_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float sq_tanh(float x) {
+  const float big = 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f);
+  const float x2 = x * x;
+  const float small = x * (1.f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * (-0.053968254f + x2 * 0.021869488f))));
+  return fabsf(x) < 0.25f ? small : big;
+}
 constexpr int SQ_H = 128, SQ_G = 512, SQ_XG = 72;      // SQ_XG: row stride of the wave-local gate exchange
 
 struct SeqFwdInst {
@@ -446,9 +457,9 @@ constexpr int SQ_SLAB = 512 * 33 + 64;                 // one 32-column slab of 
 template <int OPAD>
 __global__ __launch_bounds__(512) void lstm_seq_forward_kernel(SeqFwdGroup grp, int B, int T, int chunks, int gx_r) {
   constexpr int H = SQ_H, G = SQ_G, LD = H + 4;           // LD * 4 bytes is a multiple of 16
-  // dynamic LDS: the weight slab of the prologue, later (same memory) the window's observations [T][4][OPAD] of the four rows
+  // dynamic LDS: the weight slab of the prologue, then the window's observations [T][4][OPAD] of the four rows
   extern __shared__ __attribute__((aligned(16))) float dyn[];
-  float* xall = dyn;
+  float* xall = dyn + SQ_SLAB;
   __shared__ __attribute__((aligned(16))) float hs[2][4][LD];     // h_{t-1} / h_t of the four rows
   __shared__ float xg[8][4][SQ_XG];
   const SeqFwdInst& g = grp.in[blockIdx.z];
@@ -460,7 +471,7 @@ __global__ __launch_bounds__(512) void lstm_seq_forward_kernel(SeqFwdGroup grp, 
   if ((int)blockIdx.x < gx_r) {
     // ---- reverse direction: one step from the zero state on x[T-1]; thread = gate column.  These workgroups come
     // first in dispatch order and are few (each takes several groups of rows): they are done within microseconds.
-    float (*pre_r)[G + 4] = reinterpret_cast<float (*)[G + 4]>(dyn + 4 * OPAD);
+    float (*pre_r)[G + 4] = reinterpret_cast<float (*)[G + 4]>(dyn);
     float wr[OPAD];
 #pragma unroll
     for (int c = 0; c < OPAD; ++c) wr[c] = c < o ? g.w_ih_r[(long)tid * o + c] : 0.f;
@@ -501,6 +512,29 @@ __global__ __launch_bounds__(512) void lstm_seq_forward_kernel(SeqFwdGroup grp, 
   // ---- forward direction.  Matrix role: lane = (gate, unit of the wave); cell role: lane = (row, unit of the wave)
   const int mg = lane >> 4, mu = 16 * wave + (lane & 15);
   const int wrow = mg * H + mu;                            // this lane's row of W_ih / W_hh
+  // The window's observations of four rows: into LDS once, and out again time-major (the weight-gradient products
+  // read them that way); nothing is loaded from memory inside the time loop.
+  auto stage_x = [&](int r0) {
+    for (int base = 0; base < T * 4 * OPAD; base += 4 * 512) {     // four loads in flight per thread
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = base + u * 512 + tid;
+        const int xc = e % OPAD, rt = e / OPAD, xr = rt & 3, t = rt >> 2;
+        const bool in = e < T * 4 * OPAD && xc < o && r0 + xr < B;
+        v[u] = in ? g.obs[(long)(r0 + xr) * g.ldobs + (long)t * o + xc] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = base + u * 512 + tid;
+        const int xc = e % OPAD, rt = e / OPAD, xr = rt & 3, t = rt >> 2;
+        if (e < T * 4 * OPAD) {
+          xall[e] = v[u];
+          if (xc < o && r0 + xr < B) g.x_tm[((long)t * B + r0 + xr) * o + xc] = v[u];
+        }
+      }
+    }
+  };
   float wh[H], wi[OPAD];
   {
     // A lane needs one whole ROW of the weight matrices.  Read row by row from memory that is 64 cache lines per
@@ -517,18 +551,15 @@ __global__ __launch_bounds__(512) void lstm_seq_forward_kernel(SeqFwdGroup grp, 
       }
     };
     request(0);
-    // W_ih [512][o] is one contiguous block: element e -> (row e / o, column e % o), image row stride o | 1
-    const int so = o | 1;
-    for (int e = tid; e < G * o; e += 512) {
-      const int row = e / o, c = e - row * o;
-      dyn[row * so + c] = g.w_ih[e];
-    }
-    __syncthreads();
+    // W_ih: a lane's row is o contiguous floats and sixteen lanes read adjacent rows, so these go straight to registers
 #pragma unroll
-    for (int c = 0; c < OPAD; ++c) wi[c] = dyn[wrow * so + (c < o ? c : 0)];
+    for (int c = 0; c < OPAD; ++c) wi[c] = g.w_ih[(long)wrow * o + (c < o ? c : 0)];
 #pragma unroll
     for (int c = 0; c < OPAD; ++c) wi[c] = c < o ? wi[c] : 0.f;
-    __syncthreads();
+    // the first group's observations ride on the same memory round trip as the weights' first requests
+    if (bx < chunks) stage_x(bx * 4);
+    LSTM_STAMP(0, 8);
+    // the barriers of this loop wait for LDS traffic only, so the next slab's loads stay in flight across them
 #pragma unroll
     for (int slab = 0; slab < 4; ++slab) {
 #pragma unroll
@@ -538,12 +569,14 @@ __global__ __launch_bounds__(512) void lstm_seq_forward_kernel(SeqFwdGroup grp, 
         p[0] = nx[it].x; p[1] = nx[it].y; p[2] = nx[it].z; p[3] = nx[it].w;
       }
       if (slab + 1 < 4) request(slab + 1);
-      __syncthreads();
+      lds_barrier();
 #pragma unroll
       for (int k = 0; k < 32; ++k) wh[32 * slab + k] = dyn[lrow + k];
-      __syncthreads();
+      lds_barrier();
+      if (slab == 0) LSTM_STAMP(0, 9);
     }
   }
+  LSTM_STAMP(0, 10);
   const float bias = g.b_ih[wrow] + g.b_hh[wrow];
   const int crow = lane >> 4, cu = mu;                     // cell role
   const int arow = lane & 3;                               // operand A: lane 4b+i carries batch row i
@@ -551,22 +584,20 @@ __global__ __launch_bounds__(512) void lstm_seq_forward_kernel(SeqFwdGroup grp, 
   for (int chunk = bx; chunk < chunks; chunk += gx_f) {
     const int r0 = chunk * 4;
     const bool valid = r0 + crow < B;
-    // the window's observations of the four rows: into LDS once, and out again time-major (the weight-gradient
-    // products read them that way); nothing is loaded from memory inside the time loop
-    for (int e = tid; e < T * 4 * OPAD; e += 512) {
-      const int xc = e % OPAD, rt = e / OPAD, xr = rt & 3, t = rt >> 2;
-      const bool in = xc < o && r0 + xr < B;
-      const float v = in ? g.obs[(long)(r0 + xr) * g.ldobs + (long)t * o + xc] : 0.f;
-      xall[e] = v;
-      if (in) g.x_tm[((long)t * B + r0 + xr) * o + xc] = v;
-    }
+    if (chunk != bx) stage_x(r0);                          // (the first group's were requested with the weights)
     if (valid) {                                           // the zero slot of the state buffers
       g.hbuf[(long)(r0 + crow) * H + cu] = 0.f;
       g.cbuf[(long)(r0 + crow) * H + cu] = 0.f;
     }
     float c = 0.f;
+    // this thread's outputs of step 0; they advance by one time slice per step
+    const int vrow = valid ? r0 + crow : 0;
+    float* p_gate = g.gates + (long)vrow * G + cu;
+    float* p_c = g.cbuf + BH + (long)vrow * H + cu;
+    float* p_h = g.hbuf + BH + (long)vrow * H + cu;
     // Everything requested so far (weights, bias, observations) is waited for HERE: inside the loop the compiler
     // would otherwise wait for "all memory traffic" at the first use, which there includes the previous step's stores.
+    LSTM_STAMP(0, 11);
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
     lds_barrier();
     LSTM_STAMP(0, 1);
@@ -590,22 +621,23 @@ __global__ __launch_bounds__(512) void lstm_seq_forward_kernel(SeqFwdGroup grp, 
           a3 = __builtin_amdgcn_mfma_f32_4x4x1f32(v.w, wi[4 * q + 3], a3, 0, 0, 0);
         }
       } else {
-        // Blocks of four groups (16 products = 128 matrix-pipe cycles): the LDS reads of block n+1 are issued
+        // Blocks of BG groups (4 * BG products = 32 * BG matrix-pipe cycles): the LDS reads of block n+1 are issued
         // before the products of block n, so that their latency passes under them.
-        constexpr int NB = (XQ + H / 4) / 4;
-        float4 va[4], vb[4];
+        constexpr int BG = OPAD > 16 ? 2 : 4;               // groups per block (the wide form has fewer registers to spare)
+        constexpr int NB = (XQ + H / 4) / BG;
+        float4 va[BG], vb[BG];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) va[i] = group(i);
+        for (int i = 0; i < BG; ++i) va[i] = group(i);
 #pragma unroll
         for (int blk = 0; blk < NB; ++blk) {
           if (blk + 1 < NB) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) vb[i] = group(4 * (blk + 1) + i);
+            for (int i = 0; i < BG; ++i) vb[i] = group(BG * (blk + 1) + i);
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int k = 16 * blk + 4 * i;
+          for (int i = 0; i < BG; ++i) {
+            const int k = 4 * BG * blk + 4 * i;
             a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(va[i].x, weight(k), a0, 0, 0, 0);
             a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(va[i].y, weight(k + 1), a1, 0, 0, 0);
             a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(va[i].z, weight(k + 2), a2, 0, 0, 0);
@@ -613,7 +645,7 @@ __global__ __launch_bounds__(512) void lstm_seq_forward_kernel(SeqFwdGroup grp, 
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) va[i] = vb[i];
+          for (int i = 0; i < BG; ++i) va[i] = vb[i];
         }
       }
       if (t == 1) LSTM_STAMP(0, 2);
@@ -624,21 +656,22 @@ __global__ __launch_bounds__(512) void lstm_seq_forward_kernel(SeqFwdGroup grp, 
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const float* pr = &xg[wave][crow][lane & 15];
-      const float gi = sigmoidf_(pr[0]);
-      const float gf = sigmoidf_(pr[16]);
-      const float gg = tanhf(pr[32]);
-      const float go = sigmoidf_(pr[48]);
+      const float gi = sq_sigmoid(pr[0]);
+      const float gf = sq_sigmoid(pr[16]);
+      const float gg = sq_tanh(pr[32]);
+      const float go = sq_sigmoid(pr[48]);
       c = gf * c + gi * gg;
-      const float hv = go * tanhf(c);
+      const float hv = go * sq_tanh(c);
       if (t == 1) LSTM_STAMP(0, 3);
       hs[cur ^ 1][crow][cu] = hv;
       if (valid) {
-        const long rb = (long)t * B + r0 + crow;
-        float* gr = g.gates + rb * G;
-        gr[cu] = gi; gr[H + cu] = gf; gr[2 * H + cu] = gg; gr[3 * H + cu] = go;
-        g.cbuf[BH + rb * H + cu] = c;
-        g.hbuf[BH + rb * H + cu] = hv;
+        p_gate[0] = gi; p_gate[H] = gf; p_gate[2 * H] = gg; p_gate[3 * H] = go;
+        *p_c = c;
+        *p_h = hv;
         if (t == T - 1) g.cat[(long)(r0 + crow) * 2 * H + cu] = hv;
+        p_gate += (long)B * G;
+        p_c += BH;
+        p_h += BH;
       }
       if (t == 1) LSTM_STAMP(0, 4);
       lds_barrier();
@@ -700,7 +733,7 @@ __global__ __launch_bounds__(512) void lstm_seq_backward_kernel(SeqBwdGroup grp,
     float dc = 0.f;
     // cell backward of step s with hidden gradient dhv; leaves dgates_s in LDS and in memory
     auto cell = [&](int s, float dhv, float gi, float gf, float gg, float go, float cs, float cp) {
-      const float tc = tanhf(cs);
+      const float tc = sq_tanh(cs);
       const float dcv = dc + dhv * go * (1.f - tc * tc);
       const float d0 = dcv * gg * gi * (1.f - gi);
       const float d1 = dcv * cp * gf * (1.f - gf);
@@ -868,7 +901,7 @@ int hhrl_lstm_forward_group(const hhrl_lstm_desc* d, int n, int B, int T, int H,
     const int chunks = ceil_div(B, 4);
     const int gx_f = seq_grid_x(chunks, n), gx_r = gx_f >= 4 ? gx_f / 4 : 1;
     const dim3 grid(gx_r + gx_f, 1, n);
-    const size_t lds_fwd = 4 * (size_t)((T * 4 * 32 > SQ_SLAB ? T * 4 * 32 : SQ_SLAB));
+    const size_t lds_fwd = 4 * (size_t)(SQ_SLAB + T * 4 * 32);
     HHRL_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(lstm_seq_forward_kernel<16>), (int)lds_fwd, "lstm"));
     HHRL_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(lstm_seq_forward_kernel<32>), (int)lds_fwd, "lstm"));
     ProfScope ps("lstm_seq_forward_kernel", st, 2.0 * B * G * ((double)T * (H + omax) + omax) * n,

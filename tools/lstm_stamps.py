@@ -17,7 +17,7 @@ import torch
 
 from hhrl_vae_amd import _lib as L
 
-FWD = [(0, "start"), (1, "weights in registers, x_0 staged"), (2, "step 1: products"), (3, "step 1: exchange + cell"),
+FWD = [(0, "start"), (8, "W_ih requested"), (9, "first slab of W_hh in registers"), (10, "all slabs"), (11, "observations staged"), (1, "requests complete, barrier"), (2, "step 1: products"), (3, "step 1: exchange + cell"),
        (4, "step 1: stores issued"), (5, "step 1: barrier"), (6, "step 2: products"), (7, "end of last step")]
 BWD = [(0, "start"), (1, "weights in registers, last cell"), (6, "first step (all four phases)"), (2, "second step: products"),
        (3, "second step: barrier"), (4, "second step: sum + cell"), (5, "second step: barrier"), (7, "end of last step")]
