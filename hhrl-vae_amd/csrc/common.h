@@ -139,6 +139,13 @@ struct GemmArgs {
   int k_chunk;
   int act, mode;
   int a_kcontig, b_kcontig;
+  // Optional (small-product kernels only): operand A is used as A(i,k) * act'(Y(i,k)), Y addressed like A with its
+  // own strides; rowsum[i] (and rowsum2[i]) += sum over this product's reduction range of that effective A(i,k).  This is how a
+  // layer's backward products apply the activation gradient and form the bias gradient without a pass of their own.
+  const float* Y;
+  long y_si, y_sk;
+  int y_act;
+  float *rowsum, *rowsum2;       // rowsum2: a second destination of the same sums (two biases that share a gradient)
 };
 constexpr int kGemmGroupMax = 16;
 struct GemmGroup {
@@ -148,5 +155,6 @@ struct GemmGroup {
 GemmArgs gemm_args(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj, float* C, long ldc,
                    int M, int N, int K, const float* bias, int act, int mode);
 int gemm_group(const GemmArgs* gs, int n, hipStream_t st);
+bool gemm_is_small(const GemmArgs& g);        // served by the small-product kernels (which honour Y / rowsum)
 
 }  // namespace hhrl

@@ -117,6 +117,7 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& g, int bx, int b
   constexpr int NT = 64 * NW;
   __shared__ float stage[NW][2][SKC][33];
   __shared__ float part[NW][32][33];
+  __shared__ float rsum[NW][32];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // in a scalar register: what depends on it is wave-uniform
   const int r = lane & 31, h = lane >> 5;
@@ -142,7 +143,10 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& g, int bx, int b
   const int nra = min(32, g.M - i0), ncb = min(32, g.N - j0);
   // The chunks are software-pipelined: the loads of chunk n+1 are issued after chunk n has been written to
   // LDS and before its products, so one memory latency is exposed per wave instead of one per chunk.
-  float av[RPL], bv[RPL], a_tail = 0.f, b_tail = 0.f;
+  float av[RPL], bv[RPL], mv[RPL], a_tail = 0.f, b_tail = 0.f, m_tail = 0.f;
+  const bool masked = g.Y != nullptr;
+  const bool want_rs = g.rowsum != nullptr && bx == 0;
+  float rs = 0.f;
   auto request = [&](int k0) {
     const int kc = min(SKC, kend - k0);
     const int np = kc >> 1;                             // full (k, k+1) pairs in the chunk
@@ -150,9 +154,11 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& g, int bx, int b
     for (int i = 0; i < RPL; ++i) {
       av[i] = 0.f;
       bv[i] = 0.f;
+      mv[i] = 0.f;
     }
     a_tail = 0.f;
     b_tail = 0.f;
+    m_tail = 0.f;
     if (g.a_kcontig) {
       if (kl < kc) {
         const int first = hf * RPL;                     // this lane's rows: first .. first + RPL - 1
@@ -161,6 +167,14 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& g, int bx, int b
         for (int i = 0; i < RPL; ++i) {
           av[i] = *pa;
           pa += (first + i + 1 < nra) ? g.a_si : 0;
+        }
+        if (masked) {
+          const float* pm = g.Y + (long)(i0 + min(first, nra - 1)) * g.y_si + (long)(k0 + kl) * g.y_sk;
+#pragma unroll
+          for (int i = 0; i < RPL; ++i) {
+            mv[i] = *pm;
+            pm += (first + i + 1 < nra) ? g.y_si : 0;
+          }
         }
       }
     } else {
@@ -174,6 +188,18 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& g, int bx, int b
         }
       }
       if (kc & 1) a_tail = row[(long)(kc - 1) * g.a_sk];
+      if (masked) {
+        const float* mrow = g.Y + (long)(i0 + min(r, nra - 1)) * g.y_si + (long)k0 * g.y_sk;
+        if (np > 0) {
+          const float* pm = mrow + h * g.y_sk;
+#pragma unroll
+          for (int t = 0; t < RPL; ++t) {
+            mv[t] = *pm;
+            pm += (t + 1 < np) ? 2 * g.y_sk : 0;
+          }
+        }
+        if (kc & 1) m_tail = mrow[(long)(kc - 1) * g.y_sk];
+      }
     }
     if (g.b_kcontig) {
       if (kl < kc) {
@@ -210,6 +236,21 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& g, int bx, int b
     const int kc = min(SKC, kend - k0);
     const int kc2 = (kc + 1) & ~1;
     // As[k][i] = A(i0+i, k0+k), Bs[k][j] = B(k0+k, j0+j)
+    if (masked) {                                       // one branch on the activation per chunk, not per element
+      if (g.y_act == HHRL_ACT_RELU) {
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) av[i] = mv[i] > 0.f ? av[i] : 0.f;
+        a_tail = m_tail > 0.f ? a_tail : 0.f;
+      } else if (g.y_act == HHRL_ACT_TANH) {
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) av[i] *= 1.f - mv[i] * mv[i];
+        a_tail *= 1.f - m_tail * m_tail;
+      } else if (g.y_act == HHRL_ACT_SIGMOID) {
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) av[i] *= mv[i] * (1.f - mv[i]);
+        a_tail *= m_tail * (1.f - m_tail);
+      }
+    }
     if (g.a_kcontig) {
 #pragma unroll
       for (int i = 0; i < RPL; ++i) As[kl][hf * RPL + i] = av[i];
@@ -230,15 +271,33 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& g, int bx, int b
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (k0 + SKC < kend) request(k0 + SKC);
-    for (int k = 0; k < kc2; k += 2)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k + h][r], Bs[k + h][r], acc, 0, 0, 0);
+    if (want_rs) {
+      for (int k = 0; k < kc2; k += 2) {
+        const float a = As[k + h][r];
+        rs += a;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bs[k + h][r], acc, 0, 0, 0);
+      }
+    } else {
+      for (int k = 0; k < kc2; k += 2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k + h][r], Bs[k + h][r], acc, 0, 0, 0);
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 #pragma unroll
   for (int i = 0; i < 16; ++i) part[wave][(i & 3) + 8 * (i >> 2) + 4 * h][r] = acc[i];
+  if (want_rs) {
+    rs += __shfl_xor(rs, 32);                              // the two reduction parities of a row
+    if (h == 0) rsum[wave][r] = rs;
+  }
   __syncthreads();
+  if (want_rs && tid < 32 && i0 + tid < g.M) {
+    float v = (rsum[0][tid] + rsum[1][tid]) + (rsum[2][tid] + rsum[3][tid]);
+    if (NW == 8) v += (rsum[4][tid] + rsum[5][tid]) + (rsum[6][tid] + rsum[7][tid]);
+    unsafeAtomicAdd(&g.rowsum[i0 + tid], v);
+    if (g.rowsum2) unsafeAtomicAdd(&g.rowsum2[i0 + tid], v);
+  }
   // fixed-order sum of the partial tiles (pairs first), epilogue, store
 #pragma unroll
   for (int u = 0; u < 1024 / NT; ++u) {
@@ -284,8 +343,11 @@ static int small_waves() {
 
 GemmArgs gemm_args(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj, float* C, long ldc,
                    int M, int N, int K, const float* bias, int act, int mode) {
-  return GemmArgs{A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, M, N, K, K, act, mode, a_sk == 1, b_sk == 1};
+  return GemmArgs{A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, M, N, K, K, act, mode, a_sk == 1, b_sk == 1,
+                  nullptr, 0, 0, HHRL_ACT_NONE, nullptr, nullptr};
 }
+
+bool gemm_is_small(const GemmArgs& g) { return (long)ceil_div(g.M, 32) * ceil_div(g.N, 32) <= 512; }
 
 static int gemm_one(GemmArgs g, hipStream_t st);
 
@@ -356,6 +418,7 @@ static int gemm_one(GemmArgs g, hipStream_t st) {
     else hipLaunchKernelGGL(gemm_small_kernel<4>, grid, dim3(256), 0, st, g);
     return launch_status("gemm_small_kernel");
   }
+  HHRL_REQUIRE(!g.Y && !g.rowsum, "gemm: operand mask / row sums are served by the small-product kernels only (M=%d N=%d)", M, N);
   const int TM = M > 1024 ? 2 : 1;
   const int TN = N > 64 ? 2 : 1;
   const int gx = ceil_div(N, 64 * TN), gy = ceil_div(M, 64 * TM);

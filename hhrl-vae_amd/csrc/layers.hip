@@ -200,6 +200,26 @@ int hhrl_linear_backward(const float* x, int ldx, const float* w, const float* y
   HHRL_REQUIRE(!dx || lddx >= K, "linear_backward: lddx=%d < K=%d", lddx, K);
   HHRL_REQUIRE(!dw || (x && ldx >= K), "linear_backward: dW needs x with ldx >= K");
   hipStream_t st = as_stream(stream);
+  // input and weight gradient read the same dy and write different buffers: one launch for both
+  GemmArgs g[2];
+  int m = 0;
+  if (dx) g[m++] = gemm_args(dy, lddy, 1, w, K, 1, dx, lddx, M, K, N, nullptr, HHRL_ACT_NONE, dx_accumulate ? 1 : 0);
+  if (dw) g[m++] = gemm_args(dy, 1, lddy, x, ldx, 1, dw, K, N, K, M, nullptr, HHRL_ACT_NONE, 2);
+  // When every product runs in the small-product kernels, the activation gradient is applied while they load dy
+  // and the bias gradient is the row sum of the weight-gradient product's operand: no pass of its own, dy untouched.
+  bool fuse = (act != HHRL_ACT_NONE || db) && (dw || !db) && m > 0;
+  for (int i = 0; i < m; ++i) fuse = fuse && gemm_is_small(g[i]);
+  if (fuse) {
+    for (int i = 0; i < m; ++i) {
+      if (act != HHRL_ACT_NONE) {
+        g[i].Y = y;
+        g[i].y_act = act;
+        if (g[i].mode == 2) { g[i].y_si = 1; g[i].y_sk = ldy; } else { g[i].y_si = ldy; g[i].y_sk = 1; }
+      }
+      if (g[i].mode == 2) g[i].rowsum = db;
+    }
+    return gemm_group(g, m, st);
+  }
   if (act != HHRL_ACT_NONE || db) {
     int cw = 64;
     while (cw > 1 && cw / 2 >= N) cw >>= 1;
@@ -211,11 +231,6 @@ int hhrl_linear_backward(const float* x, int ldx, const float* w, const float* y
                        rows_per_block);
     HHRL_TRY(launch_status("act_grad_colsum_kernel"));
   }
-  // input and weight gradient read the same dy and write different buffers: one launch for both
-  GemmArgs g[2];
-  int m = 0;
-  if (dx) g[m++] = gemm_args(dy, lddy, 1, w, K, 1, dx, lddx, M, K, N, nullptr, HHRL_ACT_NONE, dx_accumulate ? 1 : 0);
-  if (dw) g[m++] = gemm_args(dy, 1, lddy, x, ldx, 1, dw, K, N, K, M, nullptr, HHRL_ACT_NONE, 2);
   return gemm_group(g, m, st);
 }
 
@@ -240,6 +255,14 @@ int hhrl_linear_backward_group(const hhrl_linear_bwd_desc* d, int n, int M, void
   hipStream_t st = as_stream(stream);
   ActGradGroup ag;
   int n_ag = 0, max_n = 0, min_cw = 64;
+  // As in hhrl_linear_backward: with small products only, activation gradient and bias gradient ride in the products.
+  bool fuse = n <= kGemmGroupMax;
+  for (int i = 0; i < n && fuse; ++i) {
+    const hhrl_linear_bwd_desc& l = d[i];
+    if (l.db && !l.dw) fuse = false;
+    if (l.dx && (long)ceil_div(M, 32) * ceil_div(l.K, 32) > 512) fuse = false;
+    if (l.dw && (long)ceil_div(l.N, 32) * ceil_div(l.K, 32) > 512) fuse = false;
+  }
   for (int i = 0; i < n; ++i) {
     const hhrl_linear_bwd_desc& l = d[i];
     HHRL_REQUIRE(l.dy && l.w, "linear_backward_group: layer %d: null pointer", i);
@@ -248,7 +271,7 @@ int hhrl_linear_backward_group(const hhrl_linear_bwd_desc* d, int n, int M, void
     HHRL_REQUIRE(l.act == HHRL_ACT_NONE || (l.y && l.ldy >= l.N), "linear_backward_group: layer %d: activation gradient needs y", i);
     HHRL_REQUIRE(!l.dx || l.lddx >= l.K, "linear_backward_group: layer %d: lddx=%d < K=%d", i, l.lddx, l.K);
     HHRL_REQUIRE(!l.dw || (l.x && l.ldx >= l.K), "linear_backward_group: layer %d: dW needs x with ldx >= K", i);
-    if (l.act != HHRL_ACT_NONE || l.db) {
+    if (!fuse && (l.act != HHRL_ACT_NONE || l.db)) {
       int cw = 64;
       while (cw > 1 && cw / 2 >= l.N) cw >>= 1;
       ag.in[n_ag++] = ActGradInst{l.y, l.dy, l.db, l.ldy, l.lddy, l.N, l.act, cw};
@@ -278,8 +301,13 @@ int hhrl_linear_backward_group(const hhrl_linear_bwd_desc* d, int n, int M, void
     int m = 0;
     for (int i = 0; i < n; ++i) {
       const hhrl_linear_bwd_desc& l = d[i];
-      if (l.dx && (l.dx_accumulate ? 1 : 0) == pass)
-        g[m++] = gemm_args(l.dy, l.lddy, 1, l.w, l.K, 1, l.dx, l.lddx, M, l.K, l.N, nullptr, HHRL_ACT_NONE, pass);
+      if (l.dx && (l.dx_accumulate ? 1 : 0) == pass) {
+        g[m] = gemm_args(l.dy, l.lddy, 1, l.w, l.K, 1, l.dx, l.lddx, M, l.K, l.N, nullptr, HHRL_ACT_NONE, pass);
+        if (fuse && l.act != HHRL_ACT_NONE) {
+          g[m].Y = l.y; g[m].y_si = l.ldy; g[m].y_sk = 1; g[m].y_act = l.act;
+        }
+        ++m;
+      }
     }
     if (pass == 1) {
       // accumulating products into one buffer must not run concurrently with each other
@@ -290,7 +318,13 @@ int hhrl_linear_backward_group(const hhrl_linear_bwd_desc* d, int n, int M, void
     if (!dw_done && (m > 0 || pass == 1)) {
       for (int i = 0; i < n; ++i) {
         const hhrl_linear_bwd_desc& l = d[i];
-        if (l.dw) g[m++] = gemm_args(l.dy, 1, l.lddy, l.x, l.ldx, 1, l.dw, l.K, l.N, l.K, M, nullptr, HHRL_ACT_NONE, 2);
+        if (!l.dw) continue;
+        g[m] = gemm_args(l.dy, 1, l.lddy, l.x, l.ldx, 1, l.dw, l.K, l.N, l.K, M, nullptr, HHRL_ACT_NONE, 2);
+        if (fuse) {
+          if (l.act != HHRL_ACT_NONE) { g[m].Y = l.y; g[m].y_si = 1; g[m].y_sk = l.ldy; g[m].y_act = l.act; }
+          g[m].rowsum = l.db;
+        }
+        ++m;
       }
       dw_done = true;
     }

@@ -1028,13 +1028,28 @@ int hhrl_lstm_backward_group(const hhrl_lstm_desc* d, int n, int B, int T, int H
     // all instances of a group share lddo only by convention: the column sums take it per launch
     for (int i = 1; i < n; ++i)
       HHRL_REQUIRE(d[i].lddo == d[0].lddo, "lstm_backward: instances of a group must share lddo (%d vs %d)", d[i].lddo, d[0].lddo);
-    {
-      ProfScope ps("colsum2_kernel", st, 0.0, 4.0 * B * H * n);
-      hipLaunchKernelGGL(colsum2_kernel, dim3(ceil_div(H, 64), ceil_div(B, 64), n), dim3(256), 0, st, cg, d[0].lddo, H, 64);
-      HHRL_TRY(launch_status("colsum2_kernel(fc)"));
+    bool small = true;
+    for (int i = 0; i < n; ++i) small = small && gemm_is_small(dx[i]) && gemm_is_small(dw[i]);
+    if (small) {
+      // one launch: input- and weight-gradient products side by side, the bias gradient as the row sums of the
+      // weight-gradient product's operand
+      GemmArgs all[2 * kMaxInst];
+      for (int i = 0; i < n; ++i) {
+        dw[i].rowsum = d[i].grads[9];
+        all[2 * i] = dx[i];
+        all[2 * i + 1] = dw[i];
+      }
+      for (int base = 0; base < 2 * n; base += kGemmGroupMax)
+        HHRL_TRY(gemm_group(all + base, 2 * n - base < kGemmGroupMax ? 2 * n - base : kGemmGroupMax, st));
+    } else {
+      {
+        ProfScope ps("colsum2_kernel", st, 0.0, 4.0 * B * H * n);
+        hipLaunchKernelGGL(colsum2_kernel, dim3(ceil_div(H, 64), ceil_div(B, 64), n), dim3(256), 0, st, cg, d[0].lddo, H, 64);
+        HHRL_TRY(launch_status("colsum2_kernel(fc)"));
+      }
+      HHRL_TRY(gemm_group(dx, n, st));
+      HHRL_TRY(gemm_group(dw, n, st));
     }
-    HHRL_TRY(gemm_group(dx, n, st));
-    HHRL_TRY(gemm_group(dw, n, st));
   }
   const bool seq = seq_fits(d, n, H, T);
   if (seq) {
@@ -1090,22 +1105,22 @@ int hhrl_lstm_backward_group(const hhrl_lstm_desc* d, int n, int B, int T, int H
   // weight gradients of the whole window: rows (t,b) of dgates against x_tm / previous hidden state
   {
     GemmArgs dw[3 * kMaxInst];
-    ColsumGroup cg;
     int m = 0;
     for (int i = 0; i < n; ++i) {
       const int o = d[i].o;
       dw[m++] = gemm_args(w[i].dgates, 1, G, w[i].x_tm, o, 1, d[i].grads[0], o, G, o, T * B, nullptr, HHRL_ACT_NONE, 2);
-      dw[m++] = gemm_args(w[i].dgates, 1, G, w[i].hbuf, H, 1, d[i].grads[1], H, G, H, T * B, nullptr, HHRL_ACT_NONE, 2);
-      dw[m++] = gemm_args(w[i].dgates_r, 1, G, w[i].x_tm + (long)(T - 1) * B * o, o, 1, d[i].grads[4], o, G, o, B, nullptr,
-                          HHRL_ACT_NONE, 2);
-      cg.in[2 * i] = ColsumInst{w[i].dgates, d[i].grads[2], d[i].grads[3], T * B};
-      cg.in[2 * i + 1] = ColsumInst{w[i].dgates_r, d[i].grads[6], d[i].grads[7], B};
+      dw[m] = gemm_args(w[i].dgates, 1, G, w[i].hbuf, H, 1, d[i].grads[1], H, G, H, T * B, nullptr, HHRL_ACT_NONE, 2);
+      // bias_ih and bias_hh share a gradient, the column sums of dgates: the row sums of this product's operand
+      dw[m].rowsum = d[i].grads[2];
+      dw[m++].rowsum2 = d[i].grads[3];
+      dw[m] = gemm_args(w[i].dgates_r, 1, G, w[i].x_tm + (long)(T - 1) * B * o, o, 1, d[i].grads[4], o, G, o, B, nullptr,
+                        HHRL_ACT_NONE, 2);
+      dw[m].rowsum = d[i].grads[6];
+      dw[m++].rowsum2 = d[i].grads[7];
     }
+    // (each of these has at most 16 x 4 output tiles: always the small-product kernels, which honour rowsum)
     for (int base = 0; base < m; base += kGemmGroupMax)
       HHRL_TRY(gemm_group(dw + base, m - base < kGemmGroupMax ? m - base : kGemmGroupMax, st));
-    ProfScope ps("colsum2_kernel", st, 0.0, 4.0 * (T + 1) * B * G * n);
-    hipLaunchKernelGGL(colsum2_kernel, dim3(ceil_div(G, 64), ceil_div(T * B, 64), 2 * n), dim3(256), 0, st, cg, G, G, 64);
-    HHRL_TRY(launch_status("colsum2_kernel"));
   }
   return HHRL_OK;
 }

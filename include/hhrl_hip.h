@@ -48,7 +48,10 @@ int hhrl_linear_forward(const float* x, int ldx, const float* w, const float* b,
 
 /* Backward of the layer above (autograd of the same lines; loss.backward()
  * at algorithm.py:105, 311, 319, 513, 530, 806, 823, 1151, 1159, 1348, 1357).
- *   dy  : in  dL/dy (post-activation), out dL/d(pre-activation), in place;
+ *   dy  : in  dL/dy (post-activation).  With act != NONE its contents after the
+ *         call are unspecified: products of up to 512 output tiles of 32x32 apply
+ *         the activation gradient while they load dy and leave it as it was,
+ *         larger ones first rewrite it in place to dL/d(pre-activation);
  *   y   : the forward output (needed when act != NONE, else may be NULL);
  *   dx  : dL/dx, written (dx_accumulate=0) or added to; NULL to skip;
  *   dw,db: ADDED to (torch .grad semantics; the caller zeroes them); either

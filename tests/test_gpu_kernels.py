@@ -38,6 +38,8 @@ def _act(x, act):
     (64, 17, 128, 1), (64, 128, 128, 1), (64, 128, 1, 0), (37, 393, 512, 1), (4096, 64, 128, 1),
     (28672, 128, 32, 1), (28672, 32, 1, 3), (28672, 2, 16, 1), (28672, 1, 32, 0), (4096, 4, 128, 1),
     (640, 13, 512, 0), (64, 300, 4, 2), (1, 5, 3, 2), (5, 1, 1, 0),
+    # activation and bias gradient inside the backward products: a reduction split over workgroups, odd sizes
+    (1500, 70, 33, 3), (64, 301, 37, 2), (33, 7, 65, 1),
 ])
 def test_linear_forward_backward(env, M, K, N, act):
     lib, L, dev = env
@@ -79,6 +81,41 @@ def test_linear_forward_backward(env, M, K, N, act):
                                      dxd.data_ptr(), ldx, 1, dwd.data_ptr(), dbd.data_ptr(), M, K, N, act, st))
     scaled_close("dw2", dwd.cpu().numpy(), 2 * wt.grad.numpy(), atol_rel=5e-6)
     scaled_close("dx2", dxd[:, :K].cpu().numpy(), 2 * x.grad.numpy())
+
+
+@pytest.mark.parametrize("M,K,N,act", [(64, 393, 512, 1), (70, 33, 9, 2), (5000, 40, 24, 3)])
+def test_linear_backward_partial_outputs(env, M, K, N, act):
+    """hhrl_linear_backward with some of dx / dw / db left out gives what the full call gives for the rest
+    (small products carry the activation and bias gradients themselves, large ones take a pass of their own,
+    and a bias gradient without a weight gradient always does)."""
+    lib, L, dev = env
+    g = torch.Generator().manual_seed(M + K + N)
+    t = lambda *s: torch.randn(*s, generator=g).to(dev)
+    x, w, b, dy = t(M, K), t(N, K) / K ** 0.5, t(N), t(M, N)
+    y = torch.zeros(M, N, device=dev)
+    st = L.stream_ptr()
+    L.check(lib.hhrl_linear_forward(x.data_ptr(), K, w.data_ptr(), b.data_ptr(), y.data_ptr(), N, M, K, N, act, 0, st))
+    z = lambda *s: torch.zeros(*s, device=dev)
+
+    def run(want_dx, want_dw, want_db):
+        dx, dw, db, d = z(M, K), z(N, K), z(N), dy.clone()
+        L.check(lib.hhrl_linear_backward(x.data_ptr(), K, w.data_ptr(), y.data_ptr(), N, d.data_ptr(), N,
+                                         dx.data_ptr() if want_dx else None, K, 0, dw.data_ptr() if want_dw else None,
+                                         db.data_ptr() if want_db else None, M, K, N, act, st))
+        return dx, dw, db
+
+    dx0, dw0, db0 = run(True, True, True)
+    pre = dy * {1: (y > 0).float(), 2: 1 - y * y, 3: y * (1 - y)}[act]
+    scaled_close("dx", dx0.cpu().numpy(), (pre @ w).cpu().numpy(), atol_rel=1e-5)
+    scaled_close("dw", dw0.cpu().numpy(), (pre.t() @ x).cpu().numpy(), atol_rel=1e-5)
+    scaled_close("db", db0.cpu().numpy(), pre.sum(0).cpu().numpy(), atol_rel=1e-5)
+    for flags in [(True, False, False), (False, True, True), (False, True, False), (True, False, True), (False, False, True)]:
+        dx, dw, db = run(*flags)
+        for name, on, got, want in (("dx", flags[0], dx, dx0), ("dw", flags[1], dw, dw0), ("db", flags[2], db, db0)):
+            if on:
+                scaled_close("%s %s" % (name, flags), got.cpu().numpy(), want.cpu().numpy(), atol_rel=1e-5)
+            else:
+                assert not got.any(), "%s written although it was not asked for" % name
 
 
 def test_argument_errors(env):
