@@ -53,7 +53,8 @@ MLP3_GROUP_MAX = 8
 class LinearFwdDesc(C.Structure):
     """hhrl_linear_fwd_desc of include/hhrl_hip.h."""
     _fields_ = [("x", _P), ("ldx", _I), ("w", _P), ("b", _P), ("y", _P), ("ldy", _I),
-                ("K", _I), ("N", _I), ("act", _I), ("accumulate", _I)]
+                ("K", _I), ("N", _I), ("act", _I), ("accumulate", _I),
+                ("smooth_eps", _P), ("y2", _P), ("ldy2", _I)]
 
 
 class LinearBwdDesc(C.Structure):

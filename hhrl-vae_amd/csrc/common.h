@@ -146,6 +146,11 @@ struct GemmArgs {
   long y_si, y_sk;
   int y_act;
   float *rowsum, *rowsum2;       // rowsum2: a second destination of the same sums (two biases that share a gradient)
+  // Optional (small-product kernels, modes 0/1): target-policy smoothing of the stored value into a second output,
+  // y2[i*ldy2 + j] = clamp(C(i,j) + clamp(0.2*smooth_eps[i*N + j], -0.5, 0.5), -1, 1)
+  const float* smooth_eps;
+  float* y2;
+  long ldy2;
 };
 constexpr int kGemmGroupMax = 16;
 struct GemmGroup {

@@ -313,7 +313,13 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& g, int bx, int b
     } else {
       if (g.bias) v += bias_v[u];
       if (g.mode == 1) v += *c;
-      *c = act_apply(v, g.act);
+      v = act_apply(v, g.act);
+      *c = v;
+      if (g.smooth_eps) {
+        float n = 0.2f * g.smooth_eps[(long)gi * g.N + gj];
+        n = fminf(fmaxf(n, -0.5f), 0.5f);
+        g.y2[(long)gi * g.ldy2 + gj] = fminf(fmaxf(v + n, -1.f), 1.f);
+      }
     }
   }
 }
@@ -344,7 +350,7 @@ static int small_waves() {
 GemmArgs gemm_args(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj, float* C, long ldc,
                    int M, int N, int K, const float* bias, int act, int mode) {
   return GemmArgs{A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, M, N, K, K, act, mode, a_sk == 1, b_sk == 1,
-                  nullptr, 0, 0, HHRL_ACT_NONE, nullptr, nullptr};
+                  nullptr, 0, 0, HHRL_ACT_NONE, nullptr, nullptr, nullptr, nullptr, 0};
 }
 
 bool gemm_is_small(const GemmArgs& g) { return (long)ceil_div(g.M, 32) * ceil_div(g.N, 32) <= 512; }
@@ -418,7 +424,7 @@ static int gemm_one(GemmArgs g, hipStream_t st) {
     else hipLaunchKernelGGL(gemm_small_kernel<4>, grid, dim3(256), 0, st, g);
     return launch_status("gemm_small_kernel");
   }
-  HHRL_REQUIRE(!g.Y && !g.rowsum, "gemm: operand mask / row sums are served by the small-product kernels only (M=%d N=%d)", M, N);
+  HHRL_REQUIRE(!g.Y && !g.rowsum && !g.smooth_eps, "gemm: operand mask / row sums / smoothing are served by the small-product kernels only (M=%d N=%d)", M, N);
   const int TM = M > 1024 ? 2 : 1;
   const int TN = N > 64 ? 2 : 1;
   const int gx = ceil_div(N, 64 * TN), gy = ceil_div(M, 64 * TM);

@@ -158,6 +158,12 @@ struct CopyGroup { CopyInst in[HHRL_COPY_GROUP_MAX]; };
 __global__ void copy2d_group_kernel(CopyGroup grp, int M) {
   const CopyInst& g = grp.in[blockIdx.y];
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g.in == nullptr) {                    // a zero fill of C floats: four per thread
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (4 * idx + e < g.C) g.out[4 * idx + e] = 0.f;
+    return;
+  }
   if (idx >= (long)M * g.C) return;
   const int c = idx % g.C;
   const long r = idx / g.C;
@@ -245,8 +251,18 @@ int hhrl_linear_forward_group(const hhrl_linear_fwd_desc* d, int n, int M, void*
                  i, l.K, l.N, l.ldx, l.ldy);
     HHRL_REQUIRE(valid_act(l.act), "linear_forward_group: layer %d: bad activation %d", i, l.act);
     g[i] = gemm_args(l.x, l.ldx, 1, l.w, 1, l.K, l.y, l.ldy, M, l.N, l.K, l.b, l.act, l.accumulate ? 1 : 0);
+    HHRL_REQUIRE(!l.smooth_eps || (l.y2 && l.ldy2 >= l.N), "linear_forward_group: layer %d: smoothing needs y2 with ldy2 >= N", i);
+    if (l.smooth_eps && gemm_is_small(g[i])) {
+      g[i].smooth_eps = l.smooth_eps;
+      g[i].y2 = l.y2;
+      g[i].ldy2 = l.ldy2;
+    }
   }
-  return gemm_group(g, n, as_stream(stream));
+  HHRL_TRY(gemm_group(g, n, as_stream(stream)));
+  for (int i = 0; i < n; ++i)        // layers too large for the small-product kernels: smoothing as a launch of its own
+    if (d[i].smooth_eps && !g[i].smooth_eps)
+      HHRL_TRY(hhrl_td3_smooth_action(d[i].y, d[i].ldy, d[i].smooth_eps, d[i].y2, d[i].ldy2, M, d[i].N, stream));
+  return HHRL_OK;
 }
 
 int hhrl_linear_backward_group(const hhrl_linear_bwd_desc* d, int n, int M, void* stream) {
@@ -369,18 +385,26 @@ int hhrl_copy2d_group(const hhrl_copy_desc* d, int n, int M, void* stream) {
   HHRL_REQUIRE(d && n >= 1 && n <= HHRL_COPY_GROUP_MAX, "copy2d_group: %d blocks (1..%d supported)", n, HHRL_COPY_GROUP_MAX);
   HHRL_REQUIRE(M > 0, "copy2d_group: M=%d", M);
   CopyGroup g;
-  int cmax = 0;
+  long threads = 0;                       // of the block that needs most
   double bytes = 0.0;
   for (int i = 0; i < n; ++i) {
-    HHRL_REQUIRE(d[i].in && d[i].out, "copy2d_group: block %d: null pointer", i);
-    HHRL_REQUIRE(d[i].C > 0 && d[i].ldi >= d[i].C && d[i].ldo >= d[i].C, "copy2d_group: block %d: bad shape C=%d ldi=%d ldo=%d", i,
-                 d[i].C, d[i].ldi, d[i].ldo);
+    HHRL_REQUIRE(d[i].out, "copy2d_group: block %d: null pointer", i);
+    HHRL_REQUIRE(d[i].C > 0, "copy2d_group: block %d: C=%d", i, d[i].C);
+    long need;
+    if (d[i].in) {
+      HHRL_REQUIRE(d[i].ldi >= d[i].C && d[i].ldo >= d[i].C, "copy2d_group: block %d: bad shape C=%d ldi=%d ldo=%d", i, d[i].C, d[i].ldi,
+                   d[i].ldo);
+      need = (long)M * d[i].C;
+      bytes += 8.0 * M * d[i].C;
+    } else {
+      need = ((long)d[i].C + 3) / 4;
+      bytes += 4.0 * d[i].C;
+    }
     g.in[i] = CopyInst{d[i].in, d[i].out, d[i].ldi, d[i].ldo, d[i].C};
-    cmax = d[i].C > cmax ? d[i].C : cmax;
-    bytes += 8.0 * M * d[i].C;
+    threads = need > threads ? need : threads;
   }
   ProfScope ps("copy2d_group_kernel", as_stream(stream), 0.0, bytes);
-  hipLaunchKernelGGL(copy2d_group_kernel, dim3(ceil_div((long)M * cmax, 256), n), dim3(256), 0, as_stream(stream), g, M);
+  hipLaunchKernelGGL(copy2d_group_kernel, dim3(ceil_div(threads, 256), n), dim3(256), 0, as_stream(stream), g, M);
   return launch_status("copy2d_group_kernel");
 }
 

@@ -53,12 +53,15 @@ class Lin:
 
 
 def linear_forward_group(items, M: int) -> None:
-    """items: [(Lin, x, ldx, y, ldy)]: independent layers on the same M rows, one launch."""
+    """items: [(Lin, x, ldx, y, ldy[, smooth_eps, y2, ldy2])]: independent layers on the same M rows, one launch."""
     n = len(items)
     arr = (_lib.LinearFwdDesc * n)()
-    for d, (l, x, ldx, y, ldy) in zip(arr, items):
+    for d, it in zip(arr, items):
+        l, x, ldx, y, ldy = it[:5]
         d.x, d.ldx, d.w, d.b, d.y, d.ldy = x, ldx, l.w, l.b, y, ldy
         d.K, d.N, d.act, d.accumulate = l.K, l.N, l.act, 0
+        if len(it) > 5:                 # (..., smooth_eps, y2, ldy2): target-policy smoothing in the launch's epilogue
+            d.smooth_eps, d.y2, d.ldy2 = it[5:8]
     check(_lib.load().hhrl_linear_forward_group(arr, n, M, _lib.stream_ptr()))
 
 
@@ -206,6 +209,10 @@ class CopyQueue:
 
     def add(self, inp: int, ldi: int, out: int, ldo: int, Cc: int) -> None:
         self.items.append((inp, ldi, out, ldo, Cc))
+
+    def add_zero(self, out: int, n: int) -> None:
+        """n floats at `out` set to zero in the same launch (a gradient buffer's zero_grad)."""
+        self.items.append((None, 0, out, 0, n))
 
     def flush(self) -> None:
         lib = _lib.load()

@@ -175,6 +175,7 @@ class _CriticWork:
         self.a1, self.a2, self.q1 = e(B, h0), e(B, h1), e(B, 1)
         self.b1, self.b2, self.q2 = e(B, h0), e(B, h1), e(B, 1)
         self.d_q1, self.d_q2 = e(B, 1), e(B, 1)
+        self.d_qc, self.d_qc_value = e(B, 1), None          # dL/dQ1 of a policy step: one constant for every row
         self.d_a2, self.d_a1 = e(B, h1), e(B, h0)
         self.d_b2, self.d_b1 = e(B, h1), e(B, h0)
         self.d_xu = e(B, net.D)
@@ -332,8 +333,13 @@ class CriticNet:
                 self.mlp3[1].grads(d[1], P(w.d_q2), 1, 0.0, param_grads, None, 0)
             ops.mlp3_backward_group(d, B)
             return
+        d_q1 = P(w.d_q1)
         if dq_const is not None:
-            ops.fill(P(w.d_q1), B, dq_const)
+            # the constant gradient lives in a buffer of its own that is filled when the constant changes, not per update
+            if w.d_qc_value != dq_const:
+                ops.fill(P(w.d_qc), B, dq_const)
+                w.d_qc_value = dq_const
+            d_q1 = P(w.d_qc)
         if both_heads:
             # layer k of both heads per stage; the two first layers add up in d_xu (head 2 accumulates)
             ops.linear_backward_group([(self.l3, P(w.a2), h1, None, 0, P(w.d_q1), 1, P(w.d_a2), h1, 0),
@@ -343,7 +349,7 @@ class CriticNet:
             ops.linear_backward_group([(self.l1, P(w.xu), self.D, P(w.a1), h0, P(w.d_a1), h0, dxu, self.D, 0),
                                        (self.l4, P(w.xu), self.D, P(w.b1), h0, P(w.d_b1), h0, dxu, self.D, 1)], B, param_grads)
         else:
-            self.l3.bwd(P(w.a2), h1, None, 0, P(w.d_q1), 1, P(w.d_a2), h1, B, param_grads=param_grads)
+            self.l3.bwd(P(w.a2), h1, None, 0, d_q1, 1, P(w.d_a2), h1, B, param_grads=param_grads)
             self.l2.bwd(P(w.a1), h0, P(w.a2), h1, P(w.d_a2), h1, P(w.d_a1), h0, B, param_grads=param_grads)
             self.l1.bwd(P(w.xu), self.D, P(w.a1), h0, P(w.d_a1), h0, dxu, self.D, B, param_grads=param_grads)
         if param_grads and lstms:
@@ -772,8 +778,13 @@ class TD3Learner:
         if policy:
             for j, a in enumerate(self.actors):
                 a.stage_inputs(cq, B, obs[j][0], W, goal, W)
-        if cq.items:
-            cq.flush()
+        # zero_grad of the critic (algorithm.py:805) and, on a policy step, of every actor (:822; nothing touches an
+        # actor's gradient before its own backward pass) ride in the same launch
+        cq.add_zero(c.opt.g.base_ptr, c.opt.g.data.numel())
+        if policy:
+            for a in self.actors:
+                cq.add_zero(a.opt.g.base_ptr, a.opt.g.data.numel())
+        cq.flush()
 
         # target policies: layer k of every actor in one launch, then the smoothing noise
         for k, a in enumerate(self.actor_targets):
@@ -797,6 +808,9 @@ class TD3Learner:
             heads_early = True
             for level in (1, 2, 3):
                 items = [a.level_item(level, B, P(pi[k]), fam.a_dims[k]) for k, a in enumerate(self.actor_targets)]
+                if level == 3:              # the smoothing noise in the last layer's epilogue, straight into the target critic's input
+                    items = [it + (P(noise[k]), P(cw_t.xu, ct.act_cols[k]), ct.D) for k, it in enumerate(items)]
+                    smoothed = True
                 ops.linear_forward_group(items + c.level_items(level, B), B)
         else:
             self._actors_forward(self.actor_targets, B, [(P(pi[k]), fam.a_dims[k]) for k in range(n_a)])
@@ -806,7 +820,6 @@ class TD3Learner:
         ct.heads(B)
 
         # -- critic step: :1341-1350 / 799-808; target value, both losses and their gradients in one launch
-        c.opt.zero_grad()
         if not heads_early:
             c.heads(B)
         check(lib.hhrl_td3_target_mse(P(cw_t.q1), P(cw_t.q2), R(self.col_reward), W, fam.gamma, P(cw.q1), P(cw.q2), inv_n,
@@ -835,7 +848,6 @@ class TD3Learner:
                 a = self.actors[i]
                 c.heads(B, q1_only=True)
                 c.backward(B, both_heads=False, param_grads=False, dq_const=-inv_n)       # d(-mean Q1)/dQ1
-                a.opt.zero_grad()
                 a.backward(B, P(cw.xu, c.act_cols[i]), c.D, P(cw.d_xu, c.act_cols[i]), c.D, lstm=False)
                 if a.lstm is not None:
                     self._lstm_backward([a.lstm_bwd_item(B)], B)

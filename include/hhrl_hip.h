@@ -77,6 +77,9 @@ typedef struct {
   const float* w; const float* b;
   float* y; int ldy;
   int K, N, act, accumulate;
+  /* optional (NULL = off): the target-policy smoothing of hhrl_td3_smooth_action applied to the layer's output in the
+   * same launch: y2[row*ldy2 + col] = clamp(y + clamp(0.2*smooth_eps[row*N + col], -0.5, 0.5), -1, 1) */
+  const float* smooth_eps; float* y2; int ldy2;
 } hhrl_linear_fwd_desc;
 typedef struct {
   const float* x; int ldx;
@@ -102,6 +105,8 @@ int hhrl_copy2d(const float* in, int ldi, float* out, int ldo, int M, int C, voi
 /* Several such copies of M rows each in one launch (every torch.cat piece of an update that
  * depends only on the sampled rows). */
 #define HHRL_COPY_GROUP_MAX 32
+/* A block with in == NULL is a zero fill instead: out[0..C) = 0, one contiguous run (ldi, ldo and M do not apply):
+ * optimizer.zero_grad() (algorithm.py:310, 318, 512, 529, 805, 822, 1150, 1158, 1347, 1356) riding in the same launch. */
 typedef struct { const float* in; int ldi; float* out; int ldo; int C; } hhrl_copy_desc;
 int hhrl_copy2d_group(const hhrl_copy_desc* blocks, int n, int M, void* stream);
 /* out[r][0..C) = in[idx[r]][0..C) for r < M: the minibatch gather `self.memory[indices, :]`
