@@ -116,8 +116,10 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& g, int bx, int b
   constexpr int RPL = SKC / 2;                      // operand elements per lane per chunk: 64 lanes x RPL = 32 x SKC
   constexpr int NT = 64 * NW;
   __shared__ float stage[NW][2][SKC][33];
-  __shared__ float part[NW][32][33];
   __shared__ float rsum[NW][32];
+  // the partial output tile of a wave takes the place of its own staging buffers once its products are done
+  // (67 KB of LDS per workgroup instead of 101 KB: two workgroups per CU)
+  auto part = [&](int w) -> float (*)[33] { return stage[w][0]; };
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // in a scalar register: what depends on it is wave-uniform
   const int r = lane & 31, h = lane >> 5;
@@ -286,7 +288,7 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& g, int bx, int b
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 #pragma unroll
-  for (int i = 0; i < 16; ++i) part[wave][(i & 3) + 8 * (i >> 2) + 4 * h][r] = acc[i];
+  for (int i = 0; i < 16; ++i) part(wave)[(i & 3) + 8 * (i >> 2) + 4 * h][r] = acc[i];
   if (want_rs) {
     rs += __shfl_xor(rs, 32);                              // the two reduction parities of a row
     if (h == 0) rsum[wave][r] = rs;
@@ -305,8 +307,8 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& g, int bx, int b
     const int row = idx >> 5, col = idx & 31;
     const int gi = i0 + row, gj = j0 + col;
     if (gi >= g.M || gj >= g.N) continue;
-    float v = (part[0][row][col] + part[1][row][col]) + (part[2][row][col] + part[3][row][col]);
-    if (NW == 8) v += (part[4][row][col] + part[5][row][col]) + (part[6][row][col] + part[7][row][col]);
+    float v = (part(0)[row][col] + part(1)[row][col]) + (part(2)[row][col] + part(3)[row][col]);
+    if (NW == 8) v += (part(4)[row][col] + part(5)[row][col]) + (part(6)[row][col] + part(7)[row][col]);
     float* c = g.C + (long)gi * g.ldc + gj;
     if (g.mode == 2) {
       unsafeAtomicAdd(c, v);
@@ -335,6 +337,186 @@ __global__ __launch_bounds__(64 * NW) void gemm_small_group_kernel(GemmGroup grp
   const GemmArgs& g = grp.g[inst];
   if ((int)blockIdx.x * 32 >= g.N || (int)blockIdx.y * 32 >= g.M || bz * g.k_chunk >= g.K) return;
   gemm_small_body<NW>(g, blockIdx.x, blockIdx.y, bz);
+}
+
+// The same for products with FEW output tiles (a batch-64 layer of 400 outputs is 26 tiles of 32 x 32: a tenth of
+// the CUs, each with 8 x 32 matrix instructions of 64 cycles in a row): 16 x 16 output tiles on
+// v_mfma_f32_16x16x4_f32, four times the workgroups, a quarter of the matrix-pipe time and half the operand bytes
+// per workgroup.  Eight waves split the reduction range; operand chunks of 32 are staged in wave-private LDS
+// ([k][row], stride 17), the partial tiles are summed in wave order.  Honours the same options as the 32 x 32 form.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gemm_tiny_body(const GemmArgs& g, int bx, int by, int bz) {
+  constexpr int NW = 8, SKC = 32;
+  __shared__ float stage[NW][2][SKC][17];
+  __shared__ float rsum[NW][16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i0 = by * 16, j0 = bx * 16;
+  const int zbeg = bz * g.k_chunk;
+  const int zend = min(g.K, zbeg + g.k_chunk);
+  const int span = (((zend - zbeg + NW - 1) / NW) + 3) & ~3;       // this wave's share, a multiple of 4 except at the end
+  const int kbeg = min(zend, zbeg + wave * span), kend = min(zend, kbeg + span);
+  float (*As)[17] = stage[wave][0];
+  float (*Bs)[17] = stage[wave][1];
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int nra = min(16, g.M - i0), ncb = min(16, g.N - j0);
+  // Lane roles while staging.  An operand that is contiguous along the reduction: lane = (k of the chunk, half of
+  // the 16 rows), eight rows each; otherwise lane = (row, k mod 4), k = kq + 4 t.  Rows / columns beyond the matrix
+  // are clamped to the last valid one (they feed outputs that are never stored); k beyond the range reads as zero.
+  const int kl = lane & 31, hf = lane >> 5;
+  const int rr = lane & 15, kq = lane >> 4;
+  const bool masked = g.Y != nullptr;
+  const bool want_rs = g.rowsum != nullptr && bx == 0;
+  float rs = 0.f;
+  float av[8], bv[8], mv[8];
+  auto request = [&](int k0) {
+    const int kc = min(SKC, kend - k0);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      av[t] = 0.f;
+      bv[t] = 0.f;
+      mv[t] = 0.f;
+    }
+    if (g.a_kcontig) {
+      if (kl < kc) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const long row = i0 + min(8 * hf + t, nra - 1);
+          av[t] = g.A[row * g.a_si + (k0 + kl)];
+          if (masked) mv[t] = g.Y[row * g.y_si + (long)(k0 + kl) * g.y_sk];
+        }
+      }
+    } else {
+      const long row = i0 + min(rr, nra - 1);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int k = kq + 4 * t;
+        if (k < kc) {
+          av[t] = g.A[row * g.a_si + (long)(k0 + k) * g.a_sk];
+          if (masked) mv[t] = g.Y[row * g.y_si + (long)(k0 + k) * g.y_sk];
+        }
+      }
+    }
+    if (g.b_kcontig) {
+      if (kl < kc) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const long col = j0 + min(8 * hf + t, ncb - 1);
+          bv[t] = g.B[col * g.b_sj + (k0 + kl)];
+        }
+      }
+    } else {
+      const long col = j0 + min(rr, ncb - 1);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int k = kq + 4 * t;
+        if (k < kc) bv[t] = g.B[(long)(k0 + k) * g.b_sk + col * g.b_sj];
+      }
+    }
+  };
+  float bias_v = 0.f;
+  if (tid < 256 && g.bias && g.mode != 2 && j0 + (tid & 15) < g.N) bias_v = g.bias[j0 + (tid & 15)];
+  if (kbeg < kend) request(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += SKC) {
+    const int kc = min(SKC, kend - k0);
+    const int kc4 = (kc + 3) & ~3;
+    if (masked) {
+      if (g.y_act == HHRL_ACT_RELU) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) av[t] = mv[t] > 0.f ? av[t] : 0.f;
+      } else if (g.y_act == HHRL_ACT_TANH) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) av[t] *= 1.f - mv[t] * mv[t];
+      } else if (g.y_act == HHRL_ACT_SIGMOID) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) av[t] *= mv[t] * (1.f - mv[t]);
+      }
+    }
+    // every row of both images is written for every chunk (zeros beyond the chunk's k range)
+    if (g.a_kcontig) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) As[kl][8 * hf + t] = av[t];
+    } else {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) As[kq + 4 * t][rr] = av[t];
+    }
+    if (g.b_kcontig) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) Bs[kl][8 * hf + t] = bv[t];
+    } else {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) Bs[kq + 4 * t][rr] = bv[t];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (k0 + SKC < kend) request(k0 + SKC);
+    for (int k = 0; k < kc4; k += 4) {
+      const float a = As[k + kq][rr];
+      if (want_rs) rs += a;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bs[k + kq][rr], acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  // result register e of lane (j = lane & 15, q = lane >> 4) is C(4q + e, j); the partial tile takes the place of
+  // the wave's own A image
+#pragma unroll
+  for (int e = 0; e < 4; ++e) As[4 * kq + e][rr] = acc[e];
+  if (want_rs) {
+    rs += __shfl_xor(rs, 16);
+    rs += __shfl_xor(rs, 32);
+    if (lane < 16) rsum[wave][lane] = rs;
+  }
+  __syncthreads();
+  if (want_rs && tid < 16 && i0 + tid < g.M) {
+    const float v = ((rsum[0][tid] + rsum[1][tid]) + (rsum[2][tid] + rsum[3][tid])) +
+                    ((rsum[4][tid] + rsum[5][tid]) + (rsum[6][tid] + rsum[7][tid]));
+    unsafeAtomicAdd(&g.rowsum[i0 + tid], v);
+    if (g.rowsum2) unsafeAtomicAdd(&g.rowsum2[i0 + tid], v);
+  }
+  if (tid < 256) {
+    const int row = tid >> 4, col = tid & 15;
+    const int gi = i0 + row, gj = j0 + col;
+    if (gi < g.M && gj < g.N) {
+      float v = ((stage[0][0][row][col] + stage[1][0][row][col]) + (stage[2][0][row][col] + stage[3][0][row][col])) +
+                ((stage[4][0][row][col] + stage[5][0][row][col]) + (stage[6][0][row][col] + stage[7][0][row][col]));
+      float* c = g.C + (long)gi * g.ldc + gj;
+      if (g.mode == 2) {
+        unsafeAtomicAdd(c, v);
+      } else {
+        v += bias_v;
+        if (g.mode == 1) v += *c;
+        v = act_apply(v, g.act);
+        *c = v;
+        if (g.smooth_eps) {
+          float n = 0.2f * g.smooth_eps[(long)gi * g.N + gj];
+          n = fminf(fmaxf(n, -0.5f), 0.5f);
+          g.y2[(long)gi * g.ldy2 + gj] = fminf(fmaxf(v + n, -1.f), 1.f);
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void gemm_tiny_kernel(GemmArgs g) { gemm_tiny_body(g, blockIdx.x, blockIdx.y, blockIdx.z); }
+__global__ __launch_bounds__(512) void gemm_tiny_group_kernel(GemmGroup grp) {
+  const int inst = blockIdx.z / grp.splits, bz = blockIdx.z - inst * grp.splits;
+  const GemmArgs& g = grp.g[inst];
+  if ((int)blockIdx.x * 16 >= g.N || (int)blockIdx.y * 16 >= g.M || bz * g.k_chunk >= g.K) return;
+  gemm_tiny_body(g, blockIdx.x, blockIdx.y, bz);
+}
+
+// 16 x 16 tiles while the 32 x 32 tiles of the launch would leave three quarters of the CUs idle; HHRL_GEMM_TINY=0 turns them off.
+static bool tiny_wanted(long tiles32) {
+  static int limit = -1;
+  if (limit < 0) {
+    const char* e = getenv("HHRL_GEMM_TINY");       // 0: off; n > 1: use them up to n tiles of 32 x 32
+    limit = e ? atoi(e) : 64;
+    if (limit == 1) limit = 64;
+  }
+  return tiles32 <= limit;
 }
 
 // Waves per workgroup of the small kernels: 8 unless HHRL_GEMM_WAVES=4 asks for the four-wave form.
@@ -389,6 +571,14 @@ int gemm_group(const GemmArgs* gs, int n, hipStream_t st) {
     flops += 2.0 * gs[i].M * gs[i].N * gs[i].K;
     bytes += 4.0 * ((double)gs[i].M * gs[i].K + (double)gs[i].K * gs[i].N + (double)gs[i].M * gs[i].N);
   }
+  long tiles32 = 0;
+  for (int i = 0; i < n; ++i) tiles32 += (long)ceil_div(gs[i].M, 32) * ceil_div(gs[i].N, 32) * (gs[i].mode == 2 ? grp.splits : 1);
+  if (tiny_wanted(tiles32)) {
+    dim3 grid(ceil_div(max_n, 16), ceil_div(max_m, 16), n * grp.splits);
+    ProfScope ps("gemm_tiny_group_kernel", st, flops, bytes);
+    hipLaunchKernelGGL(gemm_tiny_group_kernel, grid, dim3(512), 0, st, grp);
+    return launch_status("gemm_tiny_group_kernel");
+  }
   dim3 grid(ceil_div(max_n, 32), ceil_div(max_m, 32), n * grp.splits);
   ProfScope ps("gemm_small_group_kernel", st, flops, bytes);
   if (small_waves() == 8) hipLaunchKernelGGL(gemm_small_group_kernel<8>, grid, dim3(512), 0, st, grp);
@@ -417,6 +607,12 @@ static int gemm_one(GemmArgs g, hipStream_t st) {
       chunk = (chunk + 7) & ~7;
       g.k_chunk = chunk;
       gz = ceil_div(K, chunk);
+    }
+    if (tiny_wanted(tiles32 * gz)) {
+      dim3 grid(ceil_div(N, 16), ceil_div(M, 16), gz);
+      ProfScope ps("gemm_tiny_kernel", st, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + (double)M * N));
+      hipLaunchKernelGGL(gemm_tiny_kernel, grid, dim3(512), 0, st, g);
+      return launch_status("gemm_tiny_kernel");
     }
     dim3 grid(ceil_div(N, 32), ceil_div(M, 32), gz);
     ProfScope ps("gemm_small_kernel", st, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + (double)M * N));
