@@ -276,8 +276,8 @@ int hhrl_linear_backward_group(const hhrl_linear_bwd_desc* d, int n, int M, void
   for (int i = 0; i < n && fuse; ++i) {
     const hhrl_linear_bwd_desc& l = d[i];
     if (l.db && !l.dw) fuse = false;
-    if (l.dx && (long)ceil_div(M, 32) * ceil_div(l.K, 32) > 512) fuse = false;
-    if (l.dw && (long)ceil_div(l.N, 32) * ceil_div(l.K, 32) > 512) fuse = false;
+    if (l.dx && !gemm_is_small(gemm_args(l.dy, l.lddy, 1, l.w, l.K, 1, l.dx, l.lddx, M, l.K, l.N, nullptr, HHRL_ACT_NONE, 0))) fuse = false;
+    if (l.dw && !gemm_is_small(gemm_args(l.dy, 1, l.lddy, l.x, l.ldx, 1, l.dw, l.K, l.N, l.K, M, nullptr, HHRL_ACT_NONE, 2))) fuse = false;
   }
   for (int i = 0; i < n; ++i) {
     const hhrl_linear_bwd_desc& l = d[i];

@@ -83,7 +83,7 @@ def test_linear_forward_backward(env, M, K, N, act):
     scaled_close("dx2", dxd[:, :K].cpu().numpy(), 2 * x.grad.numpy())
 
 
-@pytest.mark.parametrize("M,K,N,act", [(64, 393, 512, 1), (70, 33, 9, 2), (5000, 40, 24, 3)])
+@pytest.mark.parametrize("M,K,N,act", [(64, 393, 512, 1), (70, 33, 9, 2), (5000, 40, 24, 3), (70000, 130, 20, 1)])
 def test_linear_backward_partial_outputs(env, M, K, N, act):
     """hhrl_linear_backward with some of dx / dw / db left out gives what the full call gives for the rest
     (small products carry the activation and bias gradients themselves, large ones take a pass of their own,
