@@ -248,10 +248,14 @@ def test_vae_fused_matches_layerwise(B, N, g):
     eps = torch.randn(B, g, generator=torch.Generator().manual_seed(B * N)).cuda()
     lf, ll = float(ef.loss_and_grads(x, eps)), float(el.loss_and_grads(x, eps))
     assert_close("loss", lf, ll, rtol=1e-4, atol=0)
-    # two fp32 evaluations in different summation orders: elements above 2e-4 of their tensor's largest
+    # two fp32 evaluations in different summation orders: elements above 5e-4 of their tensor's largest
     # entry (1e-5 for small batches) must agree to rtol 1e-4; accuracy itself is judged against the
-    # oracle and its fp64 yardstick in test_vae_full_size_vs_oracle
-    dict_close("grad", _np(ef.grads()), _np(el.grads()), atol_rel=1e-5 if B * N < 4096 else 2e-4)
+    # oracle and its fp64 yardstick in test_vae_full_size_vs_oracle.  The allowance is not all rounding of
+    # sums: among the 3.7 M hidden pre-activations of 4096 x 7 cars one or two lie within rounding of zero,
+    # and the two paths' forward products may put such a value on different sides of the ReLU, which switches
+    # that car's whole contribution through that unit (measured: one row of func.0's input gradient, 2.4e-4 of
+    # the largest entry of decoder.0's weight gradient).
+    dict_close("grad", _np(ef.grads()), _np(el.grads()), atol_rel=1e-5 if B * N < 4096 else 5e-4)
     # same inputs, same bits: every sum of the fused step runs in a fixed order
     g1 = _np(ef.grads())
     ef.loss_and_grads(x, eps)
