@@ -172,6 +172,7 @@ class _CriticWork:
         e = lambda *s: ops.dev_empty(*s, device=dev)
         h0, h1 = net.h
         self.xu = e(B, net.D)
+        self.xu_pi = e(B, net.D)       # head input of the policy step (state, policy action) when the actor runs ahead of the critic step
         self.a1, self.a2, self.q1 = e(B, h0), e(B, h1), e(B, 1)
         self.b1, self.b2, self.q2 = e(B, h0), e(B, h1), e(B, 1)
         self.d_q1, self.d_q2 = e(B, 1), e(B, 1)
@@ -245,17 +246,19 @@ class CriticNet:
         return (self.lstms[k], P(w.d_xu, self.feat_cols[k]), self.D, w.lstm_ws[k])
 
     def stage_inputs(self, cq: "ops.CopyQueue", B: int, obs: Sequence[Tuple[int, int]], goal: Optional[int], ld_goal: int,
-                     actions: Optional[int] = None, ld_act: int = 0) -> None:
-        """Queues the copies of replay-row columns into the head input: raw observations of streams
-        without an LSTM, the goal, and (if given) the stored joint action."""
+                     actions: Optional[int] = None, ld_act: int = 0, policy_input: bool = False) -> None:
+        """Queues the copies of replay-row columns into the head input (policy_input: into the policy step's
+        own input buffer): raw observations of streams without an LSTM, the goal, and (if given) the stored
+        joint action."""
         w = self.work(B)
+        xu = w.xu_pi if policy_input else w.xu
         for k, (o_ptr, o_ld) in enumerate(obs):
             if self.lstms[k] is None:
-                cq.add(o_ptr, o_ld, P(w.xu, self.feat_cols[k]), self.D, self.fam.streams[k].o)
+                cq.add(o_ptr, o_ld, P(xu, self.feat_cols[k]), self.D, self.fam.streams[k].o)
         if self.fam.goal_dim:
-            cq.add(goal, ld_goal, P(w.xu, self.goal_col), self.D, self.fam.goal_dim)
+            cq.add(goal, ld_goal, P(xu, self.goal_col), self.D, self.fam.goal_dim)
         if actions is not None:
-            cq.add(actions, ld_act, P(w.xu, self.act_col), self.D, self.fam.act_dim)
+            cq.add(actions, ld_act, P(xu, self.act_col), self.D, self.fam.act_dim)
 
     def set_goal(self, B: int, goal: Optional[int], ld_goal: int) -> None:
         if self.fam.goal_dim:
@@ -283,21 +286,23 @@ class CriticNet:
             return [(self.l2, P(w.a1), h0, P(w.a2), h1), (self.l5, P(w.b1), h0, P(w.b2), h1)]
         return [(self.l3, P(w.a2), h1, P(w.q1), 1), (self.l6, P(w.b2), h1, P(w.q2), 1)]
 
-    def head_descs(self, d, start: int, B: int, q1_only: bool = False) -> None:
-        """Fills d[start] (and d[start + 1]) with the forward pass of head 1 (and head 2) on w.xu."""
+    def head_descs(self, d, start: int, B: int, q1_only: bool = False, policy_input: bool = False) -> None:
+        """Fills d[start] (and d[start + 1]) with the forward pass of head 1 (and head 2) on w.xu (w.xu_pi)."""
         w = self.work(B)
-        self.mlp3[0].desc(d[start], P(w.xu), self.D, P(w.q1), 1, P(w.a1), P(w.a2))
+        xu = w.xu_pi if policy_input else w.xu
+        self.mlp3[0].desc(d[start], P(xu), self.D, P(w.q1), 1, P(w.a1), P(w.a2))
         if not q1_only:
-            self.mlp3[1].desc(d[start + 1], P(w.xu), self.D, P(w.q2), 1, P(w.b1), P(w.b2))
+            self.mlp3[1].desc(d[start + 1], P(xu), self.D, P(w.q2), 1, P(w.b1), P(w.b2))
 
-    def heads(self, B: int, q1_only: bool = False) -> None:
+    def heads(self, B: int, q1_only: bool = False, policy_input: bool = False) -> None:
         w = self.work(B)
         h0, h1 = self.h
         if self.mlp3 is not None:
             d = ops.mlp3_descs(1 if q1_only else 2)
-            self.head_descs(d, 0, B, q1_only)
+            self.head_descs(d, 0, B, q1_only, policy_input)
             ops.mlp3_forward_group(d, B)
             return
+        assert not policy_input, "the policy step's own input buffer is used with the fused three-layer heads only"
         if q1_only:
             self.l1.fwd(P(w.xu), self.D, P(w.a1), h0, B)
             self.l2.fwd(P(w.a1), h0, P(w.a2), h1, B)
@@ -314,7 +319,7 @@ class CriticNet:
             self.lstms[k].bwd(P(w.d_xu, self.feat_cols[k]), self.D, w.lstm_ws[k], B)
 
     def backward(self, B: int, both_heads: bool, param_grads: bool, lstms: bool = True,
-                 dq_const: Optional[float] = None) -> None:
+                 dq_const: Optional[float] = None, policy_input: bool = False) -> None:
         """Back-propagates w.d_q1 (and w.d_q2) to w.d_xu; with param_grads also
         into the critic's gradient buffer (its LSTMs too unless lstms=False:
         the caller then runs lstm_backward per stream).  dq_const: dL/dQ1 is
@@ -326,7 +331,7 @@ class CriticNet:
         dxu = P(w.d_xu) if need_dxu else None
         if self.mlp3 is not None and not (both_heads and need_dxu):
             d = ops.mlp3_descs(2 if both_heads else 1)
-            self.mlp3[0].desc(d[0], P(w.xu), self.D, P(w.q1), 1, P(w.a1), P(w.a2))
+            self.mlp3[0].desc(d[0], P(w.xu_pi if policy_input else w.xu), self.D, P(w.q1), 1, P(w.a1), P(w.a2))
             self.mlp3[0].grads(d[0], None if dq_const is not None else P(w.d_q1), 1, dq_const or 0.0, param_grads, dxu, self.D)
             if both_heads:
                 self.mlp3[1].desc(d[1], P(w.xu), self.D, P(w.q2), 1, P(w.b1), P(w.b2))
@@ -334,6 +339,7 @@ class CriticNet:
             ops.mlp3_backward_group(d, B)
             return
         d_q1 = P(w.d_q1)
+        assert not policy_input, "the policy step's own input buffer is used with the fused three-layer heads only"
         if dq_const is not None:
             # the constant gradient lives in a buffer of its own that is filled when the constant changes, not per update
             if w.d_qc_value != dq_const:
@@ -775,9 +781,16 @@ class TD3Learner:
             a.stage_inputs(cq, B, next_obs[k][0], W, next_goal, W)
         ct.stage_inputs(cq, B, next_obs, next_goal, W)
         c.stage_inputs(cq, B, obs, goal, W, R(self.col_act), W)
+        # A single fused-MLP actor without an LSTM (the worker) does not depend on the critic step: on a policy step
+        # its forward pass rides in the first launch and writes its action into a head input of its own
+        # (state columns copied here), instead of taking a launch after the critic's optimizer step.
+        ahead = (policy and len(self.actors) == 1 and self.actors[0].mlp3 is not None and self.actors[0].lstm is None
+                 and c.mlp3 is not None and all(a.mlp3 is not None for a in self.actor_targets) and len(self.actor_targets) + 3 <= 8)
         if policy:
             for j, a in enumerate(self.actors):
                 a.stage_inputs(cq, B, obs[j][0], W, goal, W)
+            if ahead:
+                c.stage_inputs(cq, B, obs, goal, W, policy_input=True)
         # zero_grad of the critic (algorithm.py:805) and, on a policy step, of every actor (:822; nothing touches an
         # actor's gradient before its own backward pass) ride in the same launch
         cq.add_zero(c.opt.g.base_ptr, c.opt.g.data.numel())
@@ -795,12 +808,15 @@ class TD3Learner:
         heads_early = c.mlp3 is not None and all(a.mlp3 is not None for a in self.actor_targets) and n_a + 2 <= 8
         smoothed = False
         if heads_early:
-            d = ops.mlp3_descs(n_a + 2)
+            d = ops.mlp3_descs(n_a + 2 + (1 if ahead else 0))
             for k, a in enumerate(self.actor_targets):
                 a.fused_desc(d[k], B, P(pi[k]), fam.a_dims[k])
                 # the smoothing noise is applied in the launch's epilogue, straight into the target critic's input
                 d[k].smooth_eps, d[k].y2, d[k].ldy2 = P(noise[k]), P(cw_t.xu, ct.act_cols[k]), ct.D
             c.head_descs(d, n_a, B)
+            if ahead:
+                self.actors[0].bind_input(B, obs[0][0], W)
+                self.actors[0].fused_desc(d[n_a + 2], B, P(cw.xu_pi, c.act_cols[0]), c.D)
             ops.mlp3_forward_group(d, B)
             smoothed = True
         elif c.mlp3 is None and all(a.mlp3 is None for a in self.actor_targets):
@@ -841,14 +857,16 @@ class TD3Learner:
             items += [a.lstm_item(B, obs[j][0], W) for j, a in enumerate(self.actors) if a.lstm is not None]
             self._lstm_forward(items, B)
             # joint action written straight into the critic input: layer k of every actor in one launch
-            for j, a in enumerate(self.actors):
-                a.bind_input(B, obs[j][0], W)
-            self._actors_forward(self.actors, B, [(P(cw.xu, c.act_cols[j]), c.D) for j in range(len(self.actors))])
+            xu_act = cw.xu_pi if ahead else cw.xu
+            if not ahead:
+                for j, a in enumerate(self.actors):
+                    a.bind_input(B, obs[j][0], W)
+                self._actors_forward(self.actors, B, [(P(cw.xu, c.act_cols[j]), c.D) for j in range(len(self.actors))])
             for n, i in enumerate(order):
                 a = self.actors[i]
-                c.heads(B, q1_only=True)
-                c.backward(B, both_heads=False, param_grads=False, dq_const=-inv_n)       # d(-mean Q1)/dQ1
-                a.backward(B, P(cw.xu, c.act_cols[i]), c.D, P(cw.d_xu, c.act_cols[i]), c.D, lstm=False)
+                c.heads(B, q1_only=True, policy_input=ahead)
+                c.backward(B, both_heads=False, param_grads=False, dq_const=-inv_n, policy_input=ahead)       # d(-mean Q1)/dQ1
+                a.backward(B, P(xu_act, c.act_cols[i]), c.D, P(cw.d_xu, c.act_cols[i]), c.D, lstm=False)
                 if a.lstm is not None:
                     self._lstm_backward([a.lstm_bwd_item(B)], B)
                 self._allreduce(a.opt.g)
