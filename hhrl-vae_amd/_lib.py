@@ -44,7 +44,7 @@ class Mlp3Desc(C.Structure):
                 ("dy", _P), ("lddy", _I), ("dy_const", _F),
                 ("gw1", _P), ("gb1", _P), ("gw2", _P), ("gb2", _P), ("gw3", _P), ("gb3", _P),
                 ("dx", _P), ("lddx", _I),
-                ("smooth_eps", _P), ("y2", _P), ("ldy2", _I)]
+                ("smooth_eps", _P), ("y2", _P), ("ldy2", _I), ("forward_dx", _I)]
 
 
 MLP3_GROUP_MAX = 8

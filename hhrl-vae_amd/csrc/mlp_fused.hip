@@ -30,7 +30,7 @@ struct Net {
   const float* smooth_eps;
   float* y2;
   float dy_const;
-  int ldx, ldy, lddy, lddx, K0, N3, act3, ldy2;
+  int ldx, ldy, lddy, lddx, K0, N3, act3, ldy2, forward_dx;
 };
 struct NetGroup { Net in[kMaxNets]; };
 
@@ -193,6 +193,65 @@ __global__ __launch_bounds__(NT, 1) void mlp3_forward_kernel(NetGroup grp, int M
         }
       }
     }
+  }
+  if (g.forward_dx) {
+    // ---- the input gradient for dL/dy = dy_const on every row, in the same launch (the policy step's d(-mean Q)/d(action):
+    //      the network's weights and activations are in LDS already).  Same products as the backward kernel without the
+    //      parameter gradients; the hidden activations are overwritten by their gradients and not written to memory.
+    float* D3 = lds + L_Y;
+    __syncthreads();                                   // layer 3 has read h2
+#pragma unroll
+    for (int u = 0; u < 1024 / NT; ++u) {
+      const int e = u * NT + tid, rr = e >> 5, c = e & 31;
+      float v = 0.f;
+      if (c < g.N3 && row0 + rr < M) {
+        v = g.dy_const;
+        if (g.act3 != HHRL_ACT_NONE) v *= act_grad_from_output(g.y[(long)(row0 + rr) * g.ldy + c], g.act3);
+      }
+      D3[rr * 33 + c] = v;
+    }
+    __syncthreads();
+    f32x16 d[1];
+    if (mat) {                                         // dh2 = (D3 W3) o relu'(h2), column block `wave`, in place
+      d[0] = splat(0.f);
+      wave_mma<1, 32, 33, 1, H + 1, 1>(d, D3, lds + L_W3 + 32 * wave, lane);
+      wave_sync();
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float* p = lds + L_A2 + drow(i, h) * (H + 1) + 32 * wave + r;
+        *p = *p > 0.f ? d[0][i] : 0.f;
+      }
+    }
+    __syncthreads();
+    if (mat) {                                         // dh1 = (dh2 W2) o relu'(h1)
+      d[0] = splat(0.f);
+      wave_mma<1, H, H + 1, 1, H + 1, 1>(d, lds + L_A2, lds + L_W2 + 32 * wave, lane);
+    }
+    __syncthreads();                                   // every wave is done reading dh2 ... (and nobody reads h1 any more)
+    if (mat) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float* p = lds + L_A1 + drow(i, h) * (H + 1) + 32 * wave + r;
+        *p = *p > 0.f ? d[0][i] : 0.f;
+      }
+    }
+    __syncthreads();
+    {                                                  // dx = dh1 W1: 16x16 blocks over the helper waves (or waves 0..3)
+      const int xw = NT == 512 ? wave - 4 : wave;
+      if (xw >= 0) {
+        const int rb = xw & 1, j = lane & 15, q = lane >> 4;
+        for (int cb = xw >> 1; 16 * cb < K0p; cb += 2) {
+          const f32x4 c = wave_mma16<H, H + 1, 1, KMAX + 1, 1>(lds + L_A1 + 16 * rb * (H + 1), lds + L_W1 + 16 * cb, lane, 0.f);
+          const int col = 16 * cb + j;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int row = row0 + 16 * rb + 4 * q + e;
+            if (row < M && col < g.K0) g.dx[(long)row * g.lddx + col] = c[e];
+          }
+        }
+      }
+    }
+    return;
   }
   if (g.h1 != nullptr) {
     store_rows128<NT>(lds + L_A1, g.h1, row0, M, tid);
@@ -379,6 +438,7 @@ static int fill_group(NetGroup& grp, const hhrl_mlp3_desc* d, int n, int M, bool
     if (!backward) {
       HHRL_REQUIRE(s.y && s.ldy >= s.N3, "mlp3_forward: network %d: y missing or ldy=%d < N3", i, s.ldy);
       HHRL_REQUIRE(!s.smooth_eps || (s.y2 && s.ldy2 >= s.N3), "mlp3_forward: network %d: smoothing needs y2 with ldy2 >= N3", i);
+      HHRL_REQUIRE(!s.forward_dx || (s.dx && s.lddx >= s.K0), "mlp3_forward: network %d: forward_dx needs dx with lddx >= K0", i);
     } else {
       HHRL_REQUIRE(s.h1, "mlp3_backward: network %d: needs the hidden activations saved by the forward call", i);
       HHRL_REQUIRE(!s.dy || s.lddy >= s.N3, "mlp3_backward: network %d: lddy=%d < N3", i, s.lddy);
@@ -396,6 +456,7 @@ static int fill_group(NetGroup& grp, const hhrl_mlp3_desc* d, int n, int M, bool
     g.dy_const = s.dy_const;
     g.smooth_eps = backward ? nullptr : s.smooth_eps; g.y2 = s.y2; g.ldy2 = s.ldy2;
     g.ldx = s.ldx; g.ldy = s.ldy; g.lddy = s.lddy; g.lddx = s.lddx; g.K0 = s.K0; g.N3 = s.N3; g.act3 = s.act3;
+    g.forward_dx = backward ? 0 : s.forward_dx;
   }
   return HHRL_OK;
 }

@@ -312,6 +312,19 @@ class CriticNet:
         for level in (1, 2, 3):
             ops.linear_forward_group(self.level_items(level, B), B)
 
+    def q1_input_gradient(self, B: int, dq_const: float, policy_input: bool = False) -> bool:
+        """Head 1 forward and the input gradient for dL/dQ1 = dq_const on every row (w.d_xu) as ONE launch, where
+        the fused three-layer kernels serve the heads; False where they do not (the caller runs heads + backward)."""
+        if self.mlp3 is None:
+            return False
+        w = self.work(B)
+        d = ops.mlp3_descs(1)
+        self.mlp3[0].desc(d[0], P(w.xu_pi if policy_input else w.xu), self.D, P(w.q1), 1, P(w.a1), P(w.a2))
+        self.mlp3[0].grads(d[0], None, 1, dq_const, False, P(w.d_xu), self.D)
+        d[0].forward_dx = 1
+        ops.mlp3_forward_group(d, B)
+        return True
+
     def lstm_backward(self, k: int, B: int) -> None:
         """BPTT of stream k's LSTM from its columns of w.d_xu (independent of the other streams)."""
         w = self.work(B)
@@ -864,8 +877,9 @@ class TD3Learner:
                 self._actors_forward(self.actors, B, [(P(cw.xu, c.act_cols[j]), c.D) for j in range(len(self.actors))])
             for n, i in enumerate(order):
                 a = self.actors[i]
-                c.heads(B, q1_only=True, policy_input=ahead)
-                c.backward(B, both_heads=False, param_grads=False, dq_const=-inv_n, policy_input=ahead)       # d(-mean Q1)/dQ1
+                if not c.q1_input_gradient(B, -inv_n, policy_input=ahead):                                     # d(-mean Q1)/d(s, a)
+                    c.heads(B, q1_only=True, policy_input=ahead)
+                    c.backward(B, both_heads=False, param_grads=False, dq_const=-inv_n, policy_input=ahead)
                 a.backward(B, P(xu_act, c.act_cols[i]), c.D, P(cw.d_xu, c.act_cols[i]), c.D, lstm=False)
                 if a.lstm is not None:
                     self._lstm_backward([a.lstm_bwd_item(B)], B)

@@ -242,6 +242,9 @@ typedef struct {
   /* forward only, optional: the target-policy smoothing of hhrl_td3_smooth_action applied to the output in the
    * same launch: y2[row*ldy2 + col] = clamp(y + clamp(0.2*smooth_eps[row*N3 + col], -0.5, 0.5), -1, 1) */
   const float* smooth_eps; float* y2; int ldy2;
+  /* forward only, optional: nonzero = the launch also writes dx, the input gradient for dL/dy = dy_const on
+   * every row (d(-mean Q1)/d(s, a) of a policy step, algorithm.py:1353-1357), and then does not save h1 / h2 */
+  int forward_dx;
 } hhrl_mlp3_desc;
 int hhrl_mlp3_supported(int K0, int H1, int H2, int N3);
 int hhrl_mlp3_forward_group(const hhrl_mlp3_desc* nets, int n, int M, void* stream);

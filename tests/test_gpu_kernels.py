@@ -549,6 +549,16 @@ def test_mlp3_fused_matches_torch(env, M, K0, N3, act3):
         assert torch.all(dxd[:, K0:] == 0.0)
         for k, (got, want) in enumerate(zip(gd, gws)):
             scaled_close("grad[%d][%d]" % (i, k), got.cpu().numpy(), want.numpy(), atol_rel=1e-5)
+    # forward and input gradient for a constant dL/dy in ONE launch (network 1): same y and dx as the two calls above
+    d = descs[1]
+    y_two, dx_two = keep[1][6].clone(), keep[1][7].clone()
+    keep[1][6].fill_(7.0)
+    keep[1][7].zero_()
+    d.forward_dx = 1
+    L.check(lib.hhrl_mlp3_forward_group(C.pointer(d), 1, M, st))
+    d.forward_dx = 0
+    assert torch.equal(keep[1][6], y_two)
+    scaled_close("dx, one launch", keep[1][7].cpu().numpy(), dx_two.cpu().numpy(), atol_rel=1e-6)
     # input gradient only (no parameter gradients): same dx, gradient buffers untouched
     before = [t.clone() for t in keep[0][3]]
     d = descs[0]
