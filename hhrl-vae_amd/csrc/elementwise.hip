@@ -97,29 +97,51 @@ __global__ __launch_bounds__(256) void twin_mse_kernel(const float* __restrict__
 // and their gradients as in twin_mse_kernel.  ONE: a single workgroup walks all rows and stores the two losses;
 // otherwise the workgroups add their shares to a loss that was zeroed before the launch.
 template <bool ONE>
-__global__ __launch_bounds__(256) void td3_target_mse_kernel(const float* __restrict__ q1t, const float* __restrict__ q2t,
-                                                             const float* __restrict__ r, int ldr, float gamma,
-                                                             const float* __restrict__ q1, const float* __restrict__ q2,
-                                                             float inv_n, float* y, float* loss, float* dq1, float* dq2, int B) {
-  __shared__ float red[2][4];
-  const int stride = gridDim.x * blockDim.x;
+__global__ __launch_bounds__(1024) void td3_target_mse_kernel(const float* __restrict__ q1t, const float* __restrict__ q2t,
+                                                              const float* __restrict__ r, int ldr, float gamma,
+                                                              const float* __restrict__ q1, const float* __restrict__ q2,
+                                                              float inv_n, float* y, float* loss, float* dq1, float* dq2, int B) {
+  __shared__ float red[2][16];
+  const int nt = blockDim.x, stride = gridDim.x * nt;
   float s1 = 0.f, s2 = 0.f;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += stride) {
-    const float yi = r[(long)i * ldr] + gamma * fminf(q1t[i], q2t[i]);
-    y[i] = yi;
-    const float d1 = q1[i] - yi, d2 = q2[i] - yi;
-    s1 += d1 * d1;
-    s2 += d2 * d2;
-    dq1[i] = 2.f * inv_n * d1;
-    dq2[i] = 2.f * inv_n * d2;
+  // four rows per thread and pass, every load issued before the first use (one memory round trip per pass)
+  for (int base = blockIdx.x * nt + threadIdx.x; base < B; base += 4 * stride) {
+    float a[4], b[4], c[4], d[4], e[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + u * stride;
+      const bool in = i < B;
+      a[u] = in ? r[(long)i * ldr] : 0.f;
+      b[u] = in ? q1t[i] : 0.f;
+      c[u] = in ? q2t[i] : 0.f;
+      d[u] = in ? q1[i] : 0.f;
+      e[u] = in ? q2[i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + u * stride;
+      if (i >= B) continue;
+      const float yi = a[u] + gamma * fminf(b[u], c[u]);
+      y[i] = yi;
+      const float d1 = d[u] - yi, d2 = e[u] - yi;
+      s1 += d1 * d1;
+      s2 += d2 * d2;
+      dq1[i] = 2.f * inv_n * d1;
+      dq2[i] = 2.f * inv_n * d2;
+    }
   }
   s1 = wave_sum(s1);
   s2 = wave_sum(s2);
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float l1 = inv_n * (red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-    const float l2 = inv_n * (red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    float l1 = 0.f, l2 = 0.f;
+    for (int w = 0; w < nt / 64; ++w) {
+      l1 += red[0][w];
+      l2 += red[1][w];
+    }
+    l1 *= inv_n;
+    l2 *= inv_n;
     if (ONE) {
       loss[0] = l1;
       loss[1] = l2;
@@ -353,9 +375,11 @@ int hhrl_td3_target_mse(const float* q1t, const float* q2t, const float* r, int 
   HHRL_REQUIRE(B > 0 && ldr >= 1, "td3_target_mse: B=%d ldr=%d", B, ldr);
   hipStream_t st = as_stream(stream);
   ProfScope ps("td3_target_mse_kernel", st, 0.0, 32.0 * B);
-  if (B <= 8192) {
-    hipLaunchKernelGGL(td3_target_mse_kernel<true>, dim3(1), dim3(256), 0, st, q1t, q2t, r, ldr, gamma, q1, q2, inv_n, y, loss,
-                       dq1, dq2, B);
+  if (B < 2048) {
+    // one workgroup (deterministic loss, no memset); beyond, one CU's load rate on the strided reward column makes it
+    // longer than a memset node plus a grid of workgroups that add their shares (10 -> 4 us at 4096 rows)
+    hipLaunchKernelGGL(td3_target_mse_kernel<true>, dim3(1), dim3(B >= 1024 ? 1024 : 256), 0, st, q1t, q2t, r, ldr, gamma, q1, q2,
+                       inv_n, y, loss, dq1, dq2, B);
   } else {
     if (hipMemsetAsync(loss, 0, 2 * sizeof(float), st) != hipSuccess) return fail(HHRL_ERR_HIP, "td3_target_mse: memset failed");
     hipLaunchKernelGGL(td3_target_mse_kernel<false>, dim3(stream_grid(B)), dim3(256), 0, st, q1t, q2t, r, ldr, gamma, q1, q2,
