@@ -2672,14 +2672,19 @@ static int vae_step_impl(float* params, float* grads, float* m, float* v, const 
 
   // Form of the step, both ending in the slab reduction: one launch for forward, ELBO and backward while the
   // grid covers the batch with one tile of 16 lanes per workgroup (up to 4096 lanes), the four-launch form
-  // beyond (its kernels amortise their prologues over many tiles per workgroup).  HHRL_VAE_STEP=1 / =4 force
-  // one form for comparisons.
+  // beyond (its kernels amortise their prologues over many tiles per workgroup).  A workgroup of the one-launch
+  // form walks the 16 N cars of its lanes alone (measured 31 + 1.5 N us per step whatever the batch), while the
+  // four-launch form spreads the cars of a small batch over the idle CUs (64 lanes: 44 + 0.3 N us; 1024: 40 + 0.8 N;
+  // 2048: 43 + 1.0 N; 4096: 49 + 1.5 N): long lanes in small batches go to the four-launch form.
+  // HHRL_VAE_STEP=1 / =4 force one form for comparisons.
   static int step_form = -1;
   if (step_form < 0) {
     const char* e = getenv("HHRL_VAE_STEP");
     step_form = e ? atoi(e) : 0;
   }
-  if (step_form == 1 || (step_form != 4 && (B + ST_ROWS - 1) / ST_ROWS <= 256)) {
+  const int n_tiles16 = (B + ST_ROWS - 1) / ST_ROWS;
+  const bool one_launch_pays = n_tiles16 <= 256 && (N <= 12 || n_tiles16 >= 192 || (n_tiles16 >= 128 && N <= 24));
+  if (step_form == 1 || (step_form != 4 && one_launch_pays)) {
     HHRL_REQUIRE(n_flat < (1L << 31), "vae_train_step: flat buffer of %ld floats exceeds the 32-bit offsets", n_flat);
     HHRL_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(vae_step_kernel<true>), ST_LDS_FLOATS * 4, "vae_train_step"));
     HHRL_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(vae_step_kernel<false>), ST_LDS_FLOATS * 4, "vae_train_step"));
