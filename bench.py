@@ -156,7 +156,8 @@ def cpu_baseline_td3(kind: str, batch: int, budget_s: float = 4.0) -> dict:
             "sample": "%d updates of the CPU oracle's TD3 learn at batch %d (%s), %.1f s" % (n, batch, kind, dt)}
 
 
-def agent_update_rates(device, steps: int, group=None, world: int = 1, cpu_baseline: bool = True) -> dict:
+def agent_update_rates(device, steps: int, group=None, world: int = 1, cpu_baseline: bool = True,
+                       graph_collectives=None, extras: bool = True) -> dict:
     """Extra fields: TD3 update minibatches/s from synthetic replay (WorkerTD3 row width 36 and HATD3Triple
     row width 1030), each with its place on the roofline (algorithmic FLOPs and bytes from the layer shapes,
     hhrl_vae_amd/work.py) and, on one GPU, the CPU oracle's rate on the same shape.  With a process group the
@@ -168,6 +169,8 @@ def agent_update_rates(device, steps: int, group=None, world: int = 1, cpu_basel
     for name, kind, batch, n_rows in AGENT_CASES:
         progress("agent updates: %s%s" % (name, " x %d ranks" % world if group is not None else ""))
         net = _agent_net(kind, batch, n_rows, device, group)
+        if graph_collectives is not None:
+            net.graph_collectives = bool(graph_collectives)
         rank = dist.get_rank(group) if group is not None else 0
         rows = np.random.RandomState(3407 + rank).uniform(0, 1, size=(n_rows, net.fam.row_width))
         net.memory[:n_rows] = rows
@@ -221,7 +224,7 @@ def agent_update_rates(device, steps: int, group=None, world: int = 1, cpu_basel
                      "roofline": dict(work.roofline(w["flops"], w["bytes"], dt / n_timed),
                                       flops_per_update=w["flops"], bytes_per_update=w["bytes"], macs_per_row=w["macs_per_row"]),
                      "launch_forms": sorted(set(net.launch_forms().values()))}
-        if group is None:
+        if group is None and extras:
             # one policy evaluation as the agents call it every control step (host round trip included)
             fam = net.fam
             o = rows[0, :fam.streams[0].width]
@@ -245,6 +248,37 @@ def agent_update_rates(device, steps: int, group=None, world: int = 1, cpu_basel
     return out
 
 
+def one_rank_dp_probe(device, steps: int, group, agents: dict, enc_ms: float, B: int, N: int, g: int) -> dict:
+    """The data-parallel code path on ONE GPU: a one-rank RCCL group (the SUM is the identity, so the results are
+    the single-device ones) makes every update take the N-rank route -- flat-gradient all-reduce through c10d
+    between captured graph segments (or inside one graph: `graph_collective`), the separate optimizer launch
+    of the VAE step.  `dp_overhead_us` = that route's time per update minus the single-device time measured in
+    the same process: what the route itself costs before any inter-GPU traffic."""
+    from hhrl_vae_amd.algorithm import Encoder
+    out = {"backend": "nccl (RCCL), world size 1"}
+    for tag, gc in (("segments", False), ("graph_collective", True)):
+        progress("one-rank RCCL group, agent updates, collectives %s" % ("inside the graph" if gc else "between graph segments"))
+        r = agent_update_rates(device, steps, group, 1, cpu_baseline=False, graph_collectives=gc, extras=False)
+        for name, v in r.items():
+            d = out.setdefault(name, {"ms_per_update_single_device": agents[name]["ms_per_update"]})
+            d["ms_per_update_" + tag] = v["ms_per_update"]
+            d["dp_overhead_us" + ("" if not gc else "_graph_collective")] = 1e3 * (v["ms_per_update"] - agents[name]["ms_per_update"])
+            d["launch_forms_" + tag] = v["launch_forms"]
+    progress("one-rank RCCL group, VAE step")
+    enc = Encoder(2, g, device=str(device), seed=3407, group=group)
+    x = torch.from_numpy(synth_lanes(B, N, 3407)).to(device)
+    for _ in range(50):
+        enc.learn(x, sync=False, global_count=B * N)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(400):
+        enc.learn(x, sync=False, global_count=B * N)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / 400
+    out["vae_step"] = {"ms_per_step_single_device": enc_ms, "ms_per_step_dp": ms, "dp_overhead_us": 1e3 * (ms - enc_ms)}
+    return out
+
+
 def inference_latency(enc, device) -> dict:
     """Extra fields: the per-call inference surface the agents use every simulated second
     (agent.py:326, 748, 809-811): one lane encoded per call as the reference does, eight lanes of one
@@ -255,7 +289,10 @@ def inference_latency(enc, device) -> dict:
     out = {}
 
     def timed(fn, reps=200):
-        for _ in range(10):
+        # warm up by time, not by count: at least 50 ms of back-to-back calls, so that the figure is the call
+        # at the clocks the chip settles on and not its first calls after an idle stretch
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < 0.05:
             fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -343,6 +380,8 @@ def main() -> None:
     ap.add_argument("--windows", type=int, default=9, help="further timed windows of --steps steps each (spread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-agents", action="store_true")
+    ap.add_argument("--no-dp-probe", action="store_true",
+                    help="skip the one-rank RCCL pass that prices the data-parallel route (dp_one_rank in the line)")
     ap.add_argument("--rehearse", action="store_true",
                     help="N ranks on ONE GPU over gloo (exercises the N-rank path; not a scaling number)")
     args = ap.parse_args()
@@ -444,6 +483,24 @@ def main() -> None:
         agents = agent_update_rates(device, max(20, min(args.steps, 100)), group if world > 1 else None, world,
                                     cpu_baseline=not args.no_cpu_baseline)
 
+    dp_probe = None
+    if world == 1 and agents is not None and not args.no_dp_probe:
+        # the N-rank route with one rank: never allowed to take the line down
+        try:
+            import torch.distributed as dist
+            grp = group
+            if grp is None:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", str(_free_port()))
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+                grp = dist.group.WORLD
+            dp_probe = one_rank_dp_probe(device, max(20, min(args.steps, 100)), grp, agents, 1e3 * dt / args.steps, B, N, g)
+            if group is None:
+                torch.cuda.synchronize()
+                dist.destroy_process_group()
+        except Exception as e:                                   # noqa: BLE001
+            dp_probe = {"error": "%s: %s" % (type(e).__name__, e)}
+
     if rank == 0:
         kernels = {k: dict(v, ms_per_step=v["ms"] / prof_steps) for k, v in prof.items()}
         dom_name = max(kernels, key=lambda k: kernels[k]["ms"])
@@ -505,6 +562,8 @@ def main() -> None:
             out["rehearsal"] = "%d ranks on one GPU over gloo: exercises the N-rank path, not a scaling number" % world
         if agents is not None:
             out["agent_updates"] = agents
+        if dp_probe is not None:
+            out["dp_one_rank"] = dp_probe
         if world == 1 and not args.no_agents:
             out["inference"] = inference_latency(enc, device)
         if world == 1 and not args.no_cpu_baseline:

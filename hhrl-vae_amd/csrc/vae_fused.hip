@@ -2870,7 +2870,6 @@ namespace {
 constexpr int kMaxDevices = 64;
 std::mutex g_scratch_mu;
 float* g_scratch_ptr[kMaxDevices];          // device address of `scratch` on device d (nullptr: not looked up yet)
-long g_scratch_shape[kMaxDevices][4];       // (B, N, g, n_flat) of the last call on device d: the layout the array holds
 }  // namespace
 
 int hhrl_vae_train_step_noalloc(const float* params, float* grads, const long* offsets, long n_flat, const float* data,
@@ -2889,6 +2888,13 @@ int hhrl_vae_train_step_noalloc(const float* params, float* grads, const long* o
   {
     std::lock_guard<std::mutex> lock(g_scratch_mu);
     if (g_scratch_ptr[dev] == nullptr) {
+      // The address lookup is a set-up call of the runtime, not stream work: it must not happen while `st` is
+      // recording a graph.  A caller that captures makes one call on the device outside the capture first.
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(st, &cap) != hipSuccess) return fail(HHRL_ERR_HIP, "vae_train_step_noalloc: hipStreamIsCapturing failed");
+      HHRL_REQUIRE(cap == hipStreamCaptureStatusNone,
+                   "vae_train_step_noalloc: the first call on device %d resolves the scratch array's address and cannot run "
+                   "under stream capture; call once on this device outside the capture first", dev);
       float* p = nullptr;
       const hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(scratch));
       if (e != hipSuccess || p == nullptr)
@@ -2896,16 +2902,13 @@ int hhrl_vae_train_step_noalloc(const float* params, float* grads, const long* o
       g_scratch_ptr[dev] = p;
     }
     ws = g_scratch_ptr[dev];
-    // The array keeps the last call's contents.  The step reads the layout's padding (slab columns nobody
-    // writes) as zeros, and another (B, N, g, n_flat) carves the array differently: clear the part this
-    // call uses whenever the shape differs from the one the array was last carved for.
-    long* sh = g_scratch_shape[dev];
-    if (sh[0] != B || sh[1] != N || sh[2] != g || sh[3] != n_flat) {
-      if (hipMemsetAsync(ws, 0, (size_t)need * sizeof(float), st) != hipSuccess)
-        return fail(HHRL_ERR_HIP, "vae_train_step_noalloc: clearing the scratch array failed");
-      sh[0] = B; sh[1] = N; sh[2] = g; sh[3] = n_flat;
-    }
   }
+  // The array keeps the last call's contents, another (B, N, g, n_flat) carves it differently, and the step reads
+  // the layout's padding (slab columns nobody writes) as zeros.  The part this call uses is therefore cleared by
+  // EVERY call, as stream work in front of the kernels: what the array holds then never depends on which calls
+  // the host made before -- a captured call replays correctly after eager calls of other shapes in between.
+  if (hipMemsetAsync(ws, 0, (size_t)need * sizeof(float), st) != hipSuccess)
+    return fail(HHRL_ERR_HIP, "vae_train_step_noalloc: clearing the scratch array failed");
   return vae_step_impl(const_cast<float*>(params), grads, nullptr, nullptr, nullptr, offsets, n_flat, data, eps, B, N, g,
                        recon_scale, loss, ws, stream);
 }

@@ -43,8 +43,11 @@ def host_staged(group) -> bool:
     key = id(group)
     v = _host_staged.get(key)
     if v is None:
+        import os
         import torch.distributed as dist
-        v = _host_staged[key] = str(dist.get_backend(group)) == "gloo"
+        # HHRL_GLOO_DEVICE_TENSORS=1 (diagnostic, tools/dp_hang_probe.py): hand gloo the device tensor itself
+        v = str(dist.get_backend(group)) == "gloo" and os.environ.get("HHRL_GLOO_DEVICE_TENSORS") != "1"
+        _host_staged[key] = v
     return v
 
 

@@ -176,7 +176,7 @@ class _CriticWork:
         self.a1, self.a2, self.q1 = e(B, h0), e(B, h1), e(B, 1)
         self.b1, self.b2, self.q2 = e(B, h0), e(B, h1), e(B, 1)
         self.d_q1, self.d_q2 = e(B, 1), e(B, 1)
-        self.d_qc, self.d_qc_value = e(B, 1), None          # dL/dQ1 of a policy step: one constant for every row
+        self.d_qc: Dict[float, torch.Tensor] = {}           # dL/dQ1 of a policy step (one constant for every row), by constant
         self.d_a2, self.d_a1 = e(B, h1), e(B, h0)
         self.d_b2, self.d_b1 = e(B, h1), e(B, h0)
         self.d_xu = e(B, net.D)
@@ -354,11 +354,16 @@ class CriticNet:
         d_q1 = P(w.d_q1)
         assert not policy_input, "the policy step's own input buffer is used with the fused three-layer heads only"
         if dq_const is not None:
-            # the constant gradient lives in a buffer of its own that is filled when the constant changes, not per update
-            if w.d_qc_value != dq_const:
-                ops.fill(P(w.d_qc), B, dq_const)
-                w.d_qc_value = dq_const
-            d_q1 = P(w.d_qc)
+            # The constant gradient lives in a buffer of its own, one per constant (the divisor is the global batch,
+            # which a caller may vary at one B): filled once, on the first -- eager -- run of a launch chain, so a
+            # captured chain carries no fill and still reads ITS constant whatever other chains ran in between.
+            buf = w.d_qc.get(dq_const)
+            if buf is None:
+                if len(w.d_qc) >= 64:
+                    raise RuntimeError("more than 64 different global batch sizes at one shard size")
+                buf = w.d_qc[dq_const] = ops.dev_empty(B, 1, device=self.dev)
+                ops.fill(P(buf), B, dq_const)
+            d_q1 = P(buf)
         if both_heads:
             # layer k of both heads per stage; the two first layers add up in d_xu (head 2 accumulates)
             ops.linear_backward_group([(self.l3, P(w.a2), h1, None, 0, P(w.d_q1), 1, P(w.d_a2), h1, 0),
@@ -463,6 +468,10 @@ class TD3Learner:
         # data-parallel: a launch chain is captured as one graph per stretch between two all-reduces
         self._seg_graphs: Dict[tuple, list] = {}
         self._sync_hook = None
+        # graph_collectives (RCCL groups only; HHRL_DP_GRAPH_COLLECTIVE=1 or the attribute set before the first
+        # update): the gradient all-reduces are captured INSIDE one graph per update instead of running between
+        # segment graphs.  Off by default: a collective between two replays is the form every c10d backend supports.
+        self.graph_collectives = _os.environ.get("HHRL_DP_GRAPH_COLLECTIVE") == "1" and self._group_backend == "nccl"
         self._seen: Dict[tuple, int] = {}
         if use_graph not in (True, False, "auto"):
             raise ValueError("use_graph must be True, False or 'auto'")
@@ -707,6 +716,20 @@ class TD3Learner:
         graph, all-reduce, graph, ... (2 to 5 replays and 1 to 4 collectives instead of up to ~120 launches).
         The collectives stay outside the graphs: they belong to the process group's own stream handling."""
         from . import dist as hdist
+        if self.graph_collectives:
+            graph = self._graphs.get(key)
+            if graph is None:
+                if not self.use_graph or self._seen.get(key, 0) < 2:        # the eager runs also set the communicator up
+                    self._seen[key] = self._seen.get(key, 0) + 1
+                    self._update_body(st, B, policy, order)
+                    return
+                graph = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    self._update_body(st, B, policy, order)                  # _allreduce issues the collective into the capture
+                self._graphs[key] = graph
+            graph.replay()
+            return
         segs = self._seg_graphs.get(key)
         if segs is None:
             if not self.use_graph or self._seen.get(key, 0) < 2:

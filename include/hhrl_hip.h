@@ -177,8 +177,10 @@ int hhrl_vae_learn_step(float* params, float* grads, float* m, float* v, const l
  * process ends.  The call allocates and frees nothing.  Limit: hhrl_vae_workspace_floats(B, N, g, n_flat)
  * must not exceed HHRL_VAE_SCRATCH_FLOATS (every chunk of the reference's training script fits: 64 lanes of
  * up to 59 cars need 1.2 M floats); larger batches are rejected with HHRL_ERR_ARG and a message.  All calls
- * on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) race; the part
- * of the array a call uses is cleared when its shape differs from the previous call's on that GPU. */
+ * on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) race.  Every call
+ * clears the part of the array it uses as stream work ahead of its kernels (the array keeps the previous call's
+ * contents), so a captured call replays correctly whatever shapes were run in between.  The first call on a
+ * device looks the array's address up and is refused under stream capture: call once outside the capture first. */
 #define HHRL_VAE_SCRATCH_FLOATS (2 * 1024 * 1024)
 int hhrl_vae_train_step_noalloc(const float* params, float* grads, const long* offsets, long n_flat,
                                 const float* data, const float* eps, int B, int N, int g,

@@ -43,8 +43,9 @@ def td3_net(kind, group):
     import hhrl_vae_amd.algorithm as A
     if kind == "worker":                 # the reference's widths: the fused three-layer kernels
         return A.WorkerTD3(gen.cav_cfg(cap=256, batch=33, a_sched=2, c_sched=3), device="cuda:0", seed=5, group=group)
-    cfg = gen.light_cfg(o=(5, 6, 7), T=4, s=8, a=(1, 2, 3), actor_h=(12, 10), critic_h=(14, 12), batch=16, cap=64,
-                        a_sched=2, c_sched=3)
+    # the reference's widths (observations 13/13/25 over T=10, LSTM state 128, actors [400, 300], heads [512, 256]):
+    # the one-launch recurrence kernels and every product kernel form run under the group
+    cfg = gen.light_cfg(batch=16, cap=64, a_sched=2, c_sched=3)
     return A.HATD3Triple(cfg, device="cuda:0", seed=5, group=group, device_replay=True)
 
 

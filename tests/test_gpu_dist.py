@@ -93,3 +93,78 @@ def test_multi_actor_group_update_draws_one_order(group):
     for (na, sa), (nb, sb) in zip(a.state_dicts().items(), b.state_dicts().items()):
         for k in sa:
             scaled_close(na + "/" + k, sb[k].cpu().numpy(), sa[k].cpu().numpy(), rtol=1e-5, atol_rel=1e-6)
+
+
+def _pair(make, n_rows, seed=2):
+    a, b = make(None), make("group")
+    rows = np.random.RandomState(seed).uniform(0, 1, size=(n_rows, a.fam.row_width))
+    for net in (a, b):
+        net.memory[:n_rows] = rows
+        net.pointer = n_rows
+    return a, b
+
+
+@pytest.mark.parametrize("in_graph", [False, True])
+def test_worker_reference_widths_every_chain_replayed_under_rccl(group, in_graph):
+    """WorkerTD3 at the reference's widths under the one-rank RCCL group for ten updates: both launch chains
+    (plain and policy step) pass their eager runs, are captured -- as `graph, all-reduce, graph, ...` segments, or
+    (in_graph) as one graph that holds the collectives -- and are replayed several times; bit-equal to the
+    single-device learner (two workgroups per network at batch 64: a sum of two float atomics is order-free)."""
+    from hhrl_vae_amd.algorithm import WorkerTD3
+    cfg = gen.cav_cfg(cap=256)
+
+    def make(g):
+        net = WorkerTD3(cfg, device="cuda:0", seed=5, group=group if g else None)
+        if g:
+            net.graph_collectives = in_graph
+        return net
+    a, b = _pair(make, 256)
+    rs = np.random.RandomState(3)
+    for step in range(10):
+        idx = rs.randint(0, 256, size=a.batch_size)
+        noise = [rs.standard_normal((a.batch_size, d)).astype(np.float32) for d in a.fam.a_dims]
+        a.learn(indices=idx, noise=noise)
+        b.learn(indices=idx, noise=noise)
+    forms = b.launch_forms()
+    assert len(forms) == 2 and set(forms.values()) == {"graph"}, forms
+    if not in_graph:
+        assert sorted(len(s) for s in b._seg_graphs.values()) == [2, 3]       # critic | critic, actor | rest
+    for (na, sa), (nb, sb) in zip(a.state_dicts().items(), b.state_dicts().items()):
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), (na, k)
+    for (na, sa), (nb, sb) in zip(a.target_state_dicts().items(), b.target_state_dicts().items()):
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), (na, k)
+
+
+@pytest.mark.parametrize("in_graph", [False, True])
+def test_triple_reference_widths_every_chain_replayed_under_rccl(group, in_graph):
+    """HATD3Triple at the reference's widths (13/13/25 x T=10, state 128, [400, 300] actors, [512, 256] heads) under
+    the one-rank RCCL group, one actor order throughout, ten updates: the plain chain (2 segments) and the policy
+    chain (5 segments: critic, three actors, rest) are each captured and replayed three times, with the one-launch
+    recurrence kernels inside.  Against the single-device learner: equal apart from the float atomics of the
+    weight-gradient products."""
+    from hhrl_vae_amd.algorithm import HATD3Triple
+    from test_gpu_kernels import scaled_close
+    cfg = gen.light_cfg(cap=128)
+
+    def make(g):
+        net = HATD3Triple(cfg, device="cuda:0", seed=5, group=group if g else None)
+        if g:
+            net.graph_collectives = in_graph
+        return net
+    a, b = _pair(make, 128)
+    rs = np.random.RandomState(3)
+    for step in range(10):
+        idx = rs.randint(0, 128, size=a.batch_size)
+        noise = [rs.standard_normal((a.batch_size, d)).astype(np.float32) for d in a.fam.a_dims]
+        a.learn(None, indices=idx, noise=noise, order=(2, 0, 1))
+        b.learn(None, indices=idx, noise=noise, order=(2, 0, 1))
+    forms = b.launch_forms()
+    assert len(forms) == 2 and set(forms.values()) == {"graph"}, forms
+    if not in_graph:
+        assert sorted(len(s) for s in b._seg_graphs.values()) == [2, 5]
+    for get in ("state_dicts", "target_state_dicts"):
+        for (na, sa), (nb, sb) in zip(getattr(a, get)().items(), getattr(b, get)().items()):
+            for k in sa:
+                scaled_close("%s/%s/%s" % (get, na, k), sb[k].cpu().numpy(), sa[k].cpu().numpy(), rtol=1e-5, atol_rel=1e-6)

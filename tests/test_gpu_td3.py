@@ -284,6 +284,33 @@ def test_td3_device_replay_matches_host_gather():
             both_learn()
 
 
+def test_td3_alternating_global_batch_keeps_each_chains_constant():
+    """Two global batch sizes alternating at one shard size, on a family that takes the layer-by-layer path
+    (the policy step's dL/dQ1 = -1/global batch sits in a buffer that captured chains read): the replayed
+    graphs must use their own constant, as the always-eager learner does."""
+    import hhrl_vae_amd.algorithm as A
+    mk = lambda **kw: A.TD3Single(gen.light_cfg(o=(5, 5, 7), T=4, s=8, a=(1, 2, 3), actor_h=(12, 10), critic_h=(14, 12),
+                                                batch=8, cap=48), "time", seed=5, **kw)
+    graph, eager = mk(use_graph=True), mk(use_graph=False)
+    assert graph.critic.mlp3 is None
+    rows = gen.gen_rows(40, graph.fam.row_width, 3)
+    for net in (graph, eager):
+        net.memory[:40] = rows
+        net.pointer = 40
+    rs = np.random.RandomState(4)
+    for it in range(16):
+        idx = rs.randint(0, 40, size=8)
+        noise = [rs.standard_normal((8, a)).astype(np.float32) for a in graph.fam.a_dims]
+        gb = 8 if (it // 2) % 2 == 0 else 24                 # policy steps (odd `it`) alternate between the two
+        for net in (graph, eager):
+            net.learn(indices=idx, noise=noise, global_batch=gb)
+    assert set(graph.launch_forms().values()) == {"graph"} and len(graph.launch_forms()) == 4
+    a, b = graph.state_dicts(), eager.state_dicts()
+    for n in a:
+        for k in a[n]:
+            assert torch.equal(a[n][k], b[n][k]), (n, k)
+
+
 def test_td3_device_replay_default():
     """Without the argument the device mirror is used where a minibatch is wide enough to pay for it
     (batch x row width >= 32768 floats): HATD3Triple at its reference size, not WorkerTD3 at batch 64."""
