@@ -44,7 +44,8 @@ class Mlp3Desc(C.Structure):
                 ("dy", _P), ("lddy", _I), ("dy_const", _F),
                 ("gw1", _P), ("gb1", _P), ("gw2", _P), ("gb2", _P), ("gw3", _P), ("gb3", _P),
                 ("dx", _P), ("lddx", _I),
-                ("smooth_eps", _P), ("y2", _P), ("ldy2", _I), ("forward_dx", _I)]
+                ("smooth_eps", _P), ("y2", _P), ("ldy2", _I), ("forward_dx", _I),
+                ("gslab", _P), ("gslab_floats", _L)]
 
 
 MLP3_GROUP_MAX = 8
@@ -72,6 +73,7 @@ SIGNATURES = {
     "hhrl_linear_forward_group": (_I, [_P, _I, _I, _P]),
     "hhrl_linear_backward_group": (_I, [_P, _I, _I, _P]),
     "hhrl_mlp3_supported": (_I, [_I, _I, _I, _I]),
+    "hhrl_mlp3_slab_floats": (_L, [_I, _I, _I]),
     "hhrl_mlp3_forward_group": (_I, [_P, _I, _I, _P]),
     "hhrl_mlp3_backward_group": (_I, [_P, _I, _I, _P]),
     "hhrl_sum_pool": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),

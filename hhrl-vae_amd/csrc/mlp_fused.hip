@@ -1,13 +1,29 @@
 // Three dense layers (Linear+ReLU, Linear+ReLU, Linear+act) as ONE kernel per direction, for the
 // 128-wide networks of the worker agents (WorkerActor / WorkerCritic, algorithm.py:1187-1258, hidden
-// sizes from configs.py:159): a batch-64 update is bound by the number of launches, and these
-// networks fit a workgroup's LDS whole.
+// sizes from configs.py:159): a batch-64 update is bound by the number of launches, and a network's
+// 19 k parameters fit the registers of one workgroup.
 //
-// A workgroup owns 32 rows of one network (blockIdx.y = network of the group: twin Q heads, target
-// networks ... run side by side).  All three weight matrices are staged into LDS images once, the
-// activations of the chain stay in LDS; the backward kernel re-reads the saved hidden activations,
-// overwrites them with their gradients in place and adds the weight gradients of its rows to the
-// gradient buffers with float atomics.
+// Weights live in REGISTERS, activations in LDS.  A workgroup is eight waves; wave w owns output columns
+// 16w..16w+15 of both hidden layers and keeps its slices of W1, W2 (and its reduction range of W3) in
+// registers for the whole launch, loaded straight from global memory: no LDS image of the weights, no
+// staging phase, and a weight value is read once per workgroup however many rows the workgroup walks.
+// Rows are processed in tiles of 16 (v_mfma_f32_16x16x4_f32, one 16x16 output block per wave and layer), so
+// a 64-row minibatch spreads over four workgroups per network, and a 4096-row one over as many workgroups
+// as fill the chip once, each looping over its tiles with the next tile's inputs in flight.
+//
+// Operand order of a product: the four values a lane holds in one 16-byte register group are four
+// consecutive reduction indices 16m + 4q + e (q = lane/16); instruction e of group m therefore reduces over
+// {16m + 4q + e : q = 0..3} -- any assignment works as long as both operands use the same one -- and both the
+// activation rows (LDS, 16-byte reads) and the weight rows (global, 16-byte loads) are read along their
+// contiguous dimension.
+//
+// The backward kernel keeps the transposed-use slices (W3, W2 by input column; W1 for the input gradient)
+// and the weight-gradient accumulators of its column block in registers across all tiles of the
+// workgroup.  At the end a workgroup hands its share over in one of two ways: with few workgroups per
+// network (small batches) by float atomics into the gradient buffers; with many, as one row of a
+// caller-provided slab [workgroups][parameters] that mlp3_slab_reduce_kernel sums in workgroup order and
+// adds to the gradient buffers -- 256 workgroups adding 19 k floats each through atomics took four times
+// as long as the whole rest of the kernel, and the slab sum is the same bits on every run.
 #include "common.h"
 #include "mfma_tiles.h"
 
@@ -19,6 +35,8 @@ using namespace mt;
 constexpr int H = 128;          // both hidden widths
 constexpr int KMAX = 64;        // widest input
 constexpr int NMAX = 32;        // widest output
+constexpr int NT = 512;         // eight waves
+constexpr int ROWS = 16;        // rows per tile
 constexpr int kMaxNets = HHRL_MLP3_GROUP_MAX;
 
 struct Net {
@@ -29,397 +47,525 @@ struct Net {
   float *gw1, *gb1, *gw2, *gb2, *gw3, *gb3, *dx;
   const float* smooth_eps;
   float* y2;
+  float* slab;            // backward, optional: [gridDim.x][slab_floats(K0, N3)] partial parameter gradients instead of atomics
   float dy_const;
   int ldx, ldy, lddy, lddx, K0, N3, act3, ldy2, forward_dx;
 };
+// order of a network's parameter gradients inside a slab row
+__host__ __device__ inline int slab_w1(int, int) { return 0; }
+__host__ __device__ inline int slab_b1(int K0, int) { return H * K0; }
+__host__ __device__ inline int slab_w2(int K0, int) { return H * K0 + H; }
+__host__ __device__ inline int slab_b2(int K0, int) { return H * K0 + H + H * H; }
+__host__ __device__ inline int slab_w3(int K0, int) { return H * K0 + 2 * H + H * H; }
+__host__ __device__ inline int slab_b3(int K0, int N3) { return H * K0 + 2 * H + H * H + N3 * H; }
+__host__ __device__ inline int slab_floats(int K0, int N3) { return H * K0 + 2 * H + H * H + N3 * H + N3; }
 struct NetGroup { Net in[kMaxNets]; };
 
-// LDS map (floats)
-constexpr int L_W1 = 0;                         // [128][65]
-constexpr int L_W2 = L_W1 + H * (KMAX + 1);     // [128][129]
-constexpr int L_W3 = L_W2 + H * (H + 1);        // [32][129]   rows >= N3 zero
-constexpr int L_B = L_W3 + NMAX * (H + 1);      // b1[128] b2[128] b3[32]
-constexpr int L_X = L_B + 2 * H + NMAX;         // [32][65]    columns >= K0 zero
-constexpr int L_A1 = L_X + 32 * (KMAX + 1);     // [32][129]
-constexpr int L_A2 = L_A1 + 32 * (H + 1);       // [32][129]
-constexpr int L_Y = L_A2 + 32 * (H + 1);        // [32][33]
-constexpr int L_END = L_Y + 32 * 33;
-static_assert(L_END * 4 <= 163840, "the three-layer kernels must fit the 160 KiB LDS");
+// LDS map (floats).  Row strides are 4 mod 32 banks and a multiple of four floats: 16-byte reads of a row
+// by the 16 lanes of a quarter wave, and the 4-byte writes of an output block, spread over all banks.
+constexpr int LDA = H + 4;                       // hidden activation tiles [16][132]
+constexpr int LDX = KMAX + 4;                    // input tile [16][68], columns >= K0 zero
+constexpr int LDD = NMAX + 1;                    // gradient at layer 3's pre-activation [16][33], columns >= N3 zero
+constexpr int LDP = 17;                          // partial 16x16 blocks
+constexpr int NBX = KMAX / 16;                   // most 16-column blocks of the input
+constexpr int L_X = 0;
+constexpr int L_A1 = L_X + ROWS * LDX;
+constexpr int L_A2 = L_A1 + ROWS * LDA;
+constexpr int L_D3 = L_A2 + ROWS * LDA;
+constexpr int L_P = L_D3 + ROWS * LDD;           // [8 waves][<= 4 blocks][16][17]: products split over the waves by reduction range
+constexpr int L_END = L_P + 8 * NBX * 16 * LDP;
+static_assert(L_END * 4 <= 65536, "the three-layer kernels use static-size LDS");
 
-// acc[t] += A[32 x K] * B[K x 32] with a run-time reduction length (a multiple of 2)
-template <int TJ, int ASI, int ASK, int BSK, int BSJ>
-__device__ __forceinline__ void wave_mma_rt(f32x16 (&acc)[TJ], const float* a, const float* b, int lane, int K) {
-  const int r = lane & 31, h = lane >> 5;
-  const float* ap = a + r * ASI + h * ASK;
-  const float* bp = b + h * BSK + r * BSJ;
-  for (int k = 0; k < K; k += 2) {
-    const float av = ap[k * ASK];
-#pragma unroll
-    for (int t = 0; t < TJ; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[k * BSK + t * 32 * BSJ], acc[t], 0, 0, 0);
-  }
+// Diagnostic builds (-DHHRL_STAMPS): shader-clock stamps of workgroup (0, 0), thread 0; hhrl_debug_mlp_stamps() copies them out.
+#ifdef HHRL_STAMPS
+__device__ long long g_mlp_stamps[2][64];
+#define MLP_STAMP(k, i) do { const int _s = (i); if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && _s < 64) g_mlp_stamps[k][_s] = clock64(); } while (0)
+#else
+#define MLP_STAMP(k, i) do { } while (0)
+#endif
+
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ f32x4 mma4(f32x4 c, const float4& a, const float4& b) {
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, c, 0, 0, 0);
+  return c;
 }
+__device__ __forceinline__ float4 lds4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-// ---- staging helpers: every global load of a stage is issued before its first LDS write.
-//      NT = threads of the workgroup: 256, or 512 when four more waves share the copies (at one wave per
-//      SIMD the copies are bound by instruction issue); the matrix phases stay on waves 0..3.
-template <int NT>
-struct StageW {
-  float4 w2[W4Map<H, H, NT>::STEPS];        // [128][128]
-  float4 w3[W4Map<NMAX, H, NT>::STEPS];     // [N3][128], rows >= N3 zero
+// ---- weights of one wave, forward use: y[row][col0 + j] = sum_k a[row][k] * W[col0 + j][k]
+struct WFwd {
+  float4 w1[NBX];      // W1[col0 + j][16m + 4q ..]
+  float4 w2[H / 16];   // W2[col0 + j][16m + 4q ..]
+  float4 w3[NMAX / 16];// W3[16c + j][16w + 4q ..]: this wave's share of layer 3's reduction
+  float b1, b2;
 };
-template <int NT>
-__device__ __forceinline__ void request_w23(StageW<NT>& R, const Net& g, int tid) {
-  request_w4<H, H, W4Map<H, H, NT>::STEPS, NT>(R.w2, g.w2, tid);
+__device__ __forceinline__ void load_w1_fwd(WFwd& W, const Net& g, int col0, int j, int q) {
+  const float* r = g.w1 + (long)(col0 + j) * g.K0;
 #pragma unroll
-  for (int u = 0; u < W4Map<NMAX, H, NT>::STEPS; ++u) {
-    int row, col;
-    W4Map<NMAX, H, NT>::pos(tid, u, row, col);
-    R.w3[u] = row < g.N3 ? *reinterpret_cast<const float4*>(g.w3 + row * H + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int m = 0; m < NBX; ++m) {
+    const int k = 16 * m + 4 * q;
+    W.w1[m] = make_float4(k < g.K0 ? r[k] : 0.f, k + 1 < g.K0 ? r[k + 1] : 0.f, k + 2 < g.K0 ? r[k + 2] : 0.f,
+                          k + 3 < g.K0 ? r[k + 3] : 0.f);
+  }
+  W.b1 = g.b1[col0 + j];
+}
+__device__ __forceinline__ void load_w23_fwd(WFwd& W, const Net& g, int wave, int col0, int j, int q) {
+#pragma unroll
+  for (int m = 0; m < H / 16; ++m) W.w2[m] = *reinterpret_cast<const float4*>(g.w2 + (col0 + j) * H + 16 * m + 4 * q);
+  W.b2 = g.b2[col0 + j];
+#pragma unroll
+  for (int c = 0; c < NMAX / 16; ++c)
+    W.w3[c] = 16 * c + j < g.N3 ? *reinterpret_cast<const float4*>(g.w3 + (16 * c + j) * H + 16 * wave + 4 * q)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// ---- weights of one wave, backward use: dx[row][col0 + j] = sum_o d[row][o] * W[o][col0 + j]
+struct WBwd {
+  float4 w3t[NMAX / 16];   // W3[16m + 4q + e][col0 + j]
+  float4 w2t[H / 16];      // W2[16m + 4q + e][col0 + j]
+  float4 w1t[NBX];         // W1[16w + 4q + e][16c + j]: this wave's share of the input gradient's reduction
+};
+__device__ __forceinline__ void load_w_bwd(WBwd& W, const Net& g, int wave, int col0, int j, int q, bool want_dx) {
+#pragma unroll
+  for (int m = 0; m < NMAX / 16; ++m) {
+    const int n = 16 * m + 4 * q;
+    const float* p = g.w3 + (long)n * H + col0 + j;
+    W.w3t[m] = make_float4(n < g.N3 ? p[0] : 0.f, n + 1 < g.N3 ? p[H] : 0.f, n + 2 < g.N3 ? p[2 * H] : 0.f,
+                           n + 3 < g.N3 ? p[3 * H] : 0.f);
+  }
+#pragma unroll
+  for (int m = 0; m < H / 16; ++m) {
+    const float* p = g.w2 + (16 * m + 4 * q) * H + col0 + j;
+    W.w2t[m] = make_float4(p[0], p[H], p[2 * H], p[3 * H]);
+  }
+#pragma unroll
+  for (int c = 0; c < NBX; ++c) {
+    const int k = 16 * c + j;
+    const float* p = g.w1 + (long)(16 * wave + 4 * q) * g.K0 + k;
+    const bool ok = want_dx && k < g.K0;
+    W.w1t[c] = ok ? make_float4(p[0], p[g.K0], p[2 * g.K0], p[3 * g.K0]) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
-template <int NT>
-__device__ __forceinline__ void commit_w23(float* lds, const StageW<NT>& R, int tid) {
-  commit_w4<H, H, W4Map<H, H, NT>::STEPS, NT>(lds + L_W2, H + 1, R.w2, tid);
-  commit_w4<NMAX, H, W4Map<NMAX, H, NT>::STEPS, NT>(lds + L_W3, H + 1, R.w3, tid);
+
+// ---- one tile's inputs on their way from global memory to LDS (requested one tile ahead)
+struct TileIn {
+  float x[ROWS * KMAX / NT];      // 2
+  float4 h1, h2;                  // backward only
+  float d3;                       // backward only
+};
+__device__ __forceinline__ void request_x(TileIn& T, const Net& g, int row0, int M, int tid, int K0p) {
+#pragma unroll
+  for (int u = 0; u < ROWS * KMAX / NT; ++u) {
+    const int e = u * NT + tid, rr = e / K0p, c = e - rr * K0p;
+    T.x[u] = (rr < ROWS && c < g.K0 && row0 + rr < M) ? g.x[(long)(row0 + rr) * g.ldx + c] : 0.f;
+  }
 }
-// W1 [128][K0] (any K0 <= 64) and the x tile [32][K0]: element-wise, zero padding up to the even width K0p
-template <int NT>
-__device__ __forceinline__ void stage_w1_x(float* lds, const Net& g, int row0, int M, int tid, bool want_w1) {
-  const int K0 = g.K0, K0p = (K0 + 7) & ~7;
-  if (want_w1) {
-    for (int base = 0; base < H * K0p; base += 8 * NT) {
-      float v[8];
+__device__ __forceinline__ void commit_x(float* lds, const TileIn& T, int tid, int K0p) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int e = base + u * NT + tid, rr = e / K0p, c = e - rr * K0p;
-        v[u] = (e < H * K0p && c < K0) ? g.w1[rr * K0 + c] : 0.f;
-      }
+  for (int u = 0; u < ROWS * KMAX / NT; ++u) {
+    const int e = u * NT + tid, rr = e / K0p, c = e - rr * K0p;
+    if (rr < ROWS) lds[L_X + rr * LDX + c] = T.x[u];
+  }
+}
+__device__ __forceinline__ void request_bwd(TileIn& T, const Net& g, int row0, int M, int tid, int N3p) {
+  const int rr = tid >> 5, c4 = (tid & 31) * 4;
+  const bool ok = row0 + rr < M;
+  T.h1 = ok ? *reinterpret_cast<const float4*>(g.h1 + (long)(row0 + rr) * H + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  T.h2 = ok ? *reinterpret_cast<const float4*>(g.h2 + (long)(row0 + rr) * H + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int dr = tid / N3p, dc = tid - dr * N3p;
+  float v = 0.f;
+  if (dr < ROWS && dc < g.N3 && row0 + dr < M) {
+    v = g.dy ? g.dy[(long)(row0 + dr) * g.lddy + dc] : g.dy_const;
+    if (g.act3 != HHRL_ACT_NONE) v *= act_grad_from_output(g.y[(long)(row0 + dr) * g.ldy + dc], g.act3);
+  }
+  T.d3 = v;
+}
+__device__ __forceinline__ void commit_bwd(float* lds, const TileIn& T, int tid, int N3p) {
+  const int rr = tid >> 5, c4 = (tid & 31) * 4;
+  *reinterpret_cast<float4*>(lds + L_A1 + rr * LDA + c4) = T.h1;
+  *reinterpret_cast<float4*>(lds + L_A2 + rr * LDA + c4) = T.h2;
+  const int dr = tid / N3p, dc = tid - dr * N3p;
+  if (dr < ROWS) lds[L_D3 + dr * LDD + dc] = T.d3;
+}
+
+// Sum of the eight waves' partial blocks, in wave order: out(row, col) for col < 16 * nb
+__device__ __forceinline__ float sum_partials(const float* lds, int nbmax, int row, int col) {
+  const float* p = lds + L_P + (((col >> 4) * 16) + row) * LDP + (col & 15);
+  float s = 0.f;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int e = base + u * NT + tid, rr = e / K0p, c = e - rr * K0p;
-        if (e < H * K0p) lds[L_W1 + rr * (KMAX + 1) + c] = v[u];
+  for (int w = 0; w < 8; ++w) s += p[w * nbmax * 16 * LDP];
+  return s;
+}
+
+// Weight-gradient accumulators of one wave's column block (rows of dW = this wave's output columns)
+struct GradAcc {
+  f32x4 w3[NMAX / 16];   // dW3[16c + 4q + e][col0 + j]
+  f32x4 w2[H / 16];      // dW2[col0 + 4q + e][16c + j]
+  f32x4 w1[NBX];         // dW1[col0 + 4q + e][16c + j]
+  float b1, b2, b3;      // thread `tid`'s bias-gradient column (tid < 128 / N3)
+};
+
+// Backward of one tile that lies in LDS: X, A1 = h1, A2 = h2, D3.  pg: parameter gradients into `G`;
+// want_dx: the input gradient to global memory.  Leaves the tile's LDS free (ends with a barrier).
+__device__ __forceinline__ void tile_backward(float* lds, const Net& g, const WBwd& W, GradAcc& G, bool pg, bool want_dx, int row0, int M,
+                                              int tid, int nm1, int nb3) {
+  const int lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4, col0 = 16 * wave;
+  float* X = lds + L_X;
+  float* A1 = lds + L_A1;
+  float* A2 = lds + L_A2;
+  float* D3 = lds + L_D3;
+  // ---- layer 3: dW3 += D3^T h2 (own columns of h2), db3, dh2 = (D3 W3) o relu'(h2) into the own columns of A2
+  if (pg) {
+    float b[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b[e] = A2[(4 * q + e) * LDA + col0 + j];
+#pragma unroll
+    for (int c = 0; c < NMAX / 16; ++c)
+      if (c < nb3) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          G.w3[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(D3[(4 * q + e) * LDD + 16 * c + j], b[e], G.w3[c], 0, 0, 0);
       }
+    if (tid < g.N3) {
+      float s = 0.f;
+#pragma unroll
+      for (int rr = 0; rr < ROWS; ++rr) s += D3[rr * LDD + tid];
+      G.b3 += s;
     }
   }
-  float v[2048 / NT];
+  {
+    f32x4 d = zero4();
 #pragma unroll
-  for (int u = 0; u < 2048 / NT; ++u) {
-    const int e = u * NT + tid, rr = e / K0p, c = e - rr * K0p;
-    v[u] = (e < 32 * K0p && c < K0 && row0 + rr < M) ? g.x[(long)(row0 + rr) * g.ldx + c] : 0.f;
-  }
+    for (int m = 0; m < NMAX / 16; ++m)
+      if (m < nb3) {
+        const float* p = D3 + j * LDD + 16 * m + 4 * q;
+        d = mma4(d, make_float4(p[0], p[1], p[2], p[3]), W.w3t[m]);
+      }
 #pragma unroll
-  for (int u = 0; u < 2048 / NT; ++u) {
-    const int e = u * NT + tid, rr = e / K0p, c = e - rr * K0p;
-    if (e < 32 * K0p) lds[L_X + rr * (KMAX + 1) + c] = v[u];
+    for (int e = 0; e < 4; ++e) {
+      float* p = A2 + (4 * q + e) * LDA + col0 + j;
+      *p = *p > 0.f ? d[e] : 0.f;
+    }
   }
-}
-// a [32][128] tile of a row-major [M][128] matrix <-> an image with row stride 129
-template <int NT, int STEPS>
-__device__ __forceinline__ void request_rows128(float4 (&v)[STEPS], const float* src, int row0, int M, int tid) {
-  static_assert(STEPS == W4Map<32, H, NT>::STEPS, "register array does not match the tile");
+  lds_barrier();
+  // ---- layer 2: dW2 += dh2^T h1, db2, dh1 = (dh2 W2) o relu'(h1) into the own columns of A1
+  {
+    if (pg) {
+      float a[4];
 #pragma unroll
-  for (int u = 0; u < STEPS; ++u) {
-    int row, col;
-    W4Map<32, H, NT>::pos(tid, u, row, col);
-    v[u] = row0 + row < M ? *reinterpret_cast<const float4*>(src + (long)(row0 + row) * H + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-}
-template <int NT>
-__device__ __forceinline__ void store_rows128(const float* img, float* dst, int row0, int M, int tid) {
+      for (int e = 0; e < 4; ++e) a[e] = A2[(4 * q + e) * LDA + col0 + j];
 #pragma unroll
-  for (int u = 0; u < 4096 / NT; ++u) {
-    const int e = u * NT + tid, rr = e >> 7, c = e & 127;
-    if (row0 + rr < M) dst[(long)(row0 + rr) * H + c] = img[rr * (H + 1) + c];
+      for (int c = 0; c < H / 16; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          G.w2[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], A1[(4 * q + e) * LDA + 16 * c + j], G.w2[c], 0, 0, 0);
+      if (tid < H) {
+        float s = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) s += A2[rr * LDA + tid];
+        G.b2 += s;
+      }
+    }
+    f32x4 d = zero4();
+#pragma unroll
+    for (int m = 0; m < H / 16; ++m) d = mma4(d, lds4(A2 + j * LDA + 16 * m + 4 * q), W.w2t[m]);
+    lds_barrier();                                     // every wave is done reading h1 and dh2
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float* p = A1 + (4 * q + e) * LDA + col0 + j;
+      *p = *p > 0.f ? d[e] : 0.f;
+    }
   }
+  lds_barrier();
+  // ---- layer 1: dW1 += dh1^T x, db1, dx = dh1 W1 (reduction split over the waves, summed in wave order)
+  if (pg) {
+    float a[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] = A1[(4 * q + e) * LDA + col0 + j];
+#pragma unroll
+    for (int c = 0; c < NBX; ++c)
+      if (c < nm1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          G.w1[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], X[(4 * q + e) * LDX + 16 * c + j], G.w1[c], 0, 0, 0);
+      }
+    if (tid < H) {
+      float s = 0.f;
+#pragma unroll
+      for (int rr = 0; rr < ROWS; ++rr) s += A1[rr * LDA + tid];
+      G.b1 += s;
+    }
+  }
+  if (want_dx) {
+    const float4 a = lds4(A1 + j * LDA + col0 + 4 * q);
+#pragma unroll
+    for (int c = 0; c < NBX; ++c)
+      if (c < nm1) {
+        const f32x4 p = mma4(zero4(), a, W.w1t[c]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lds[L_P + ((wave * NBX + c) * 16 + 4 * q + e) * LDP + j] = p[e];
+      }
+    lds_barrier();
+    for (int o = tid; o < ROWS * 16 * nm1; o += NT) {
+      const int rr = o / (16 * nm1), col = o - rr * (16 * nm1);
+      const float s = sum_partials(lds, NBX, rr, col);
+      if (col < g.K0 && row0 + rr < M) g.dx[(long)(row0 + rr) * g.lddx + col] = s;
+    }
+  }
+  lds_barrier();
 }
 
 // ------------------------------------------------------------------ forward
-template <int NT>
-__global__ __launch_bounds__(NT, 1) void mlp3_forward_kernel(NetGroup grp, int M) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+// DX: some network of the group also wants the input gradient for a constant dL/dy (forward_dx); the plain
+// kernel does not carry the registers that takes.
+template <bool DX>
+__global__ __launch_bounds__(NT, 1) void mlp3_forward_kernel(NetGroup grp, int M, int tiles) {
+  __shared__ __attribute__((aligned(16))) float lds[L_END];
   const Net& g = grp.in[blockIdx.y];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-  const bool mat = wave < 4;                      // this wave takes part in the matrix phases
-  const int row0 = blockIdx.x * 32;
-  const int K0p = (g.K0 + 7) & ~7;
-  float* bs = lds + L_B;
-  {
-    StageW<NT> R;
-    request_w23(R, g, tid);
-    const float b1 = tid < H ? g.b1[tid] : (tid < 2 * H ? g.b2[tid - H] : 0.f);
-    const float b3 = tid < g.N3 ? g.b3[tid] : 0.f;
-    stage_w1_x<NT>(lds, g, row0, M, tid, true);
-    commit_w23(lds, R, tid);
-    if (tid < 2 * H) bs[tid] = b1;
-    if (tid < NMAX) bs[2 * H + tid] = b3;
-  }
-  __syncthreads();
-  // ---- layer 1 (K0 -> 128, ReLU): one 32-column tile per wave
-  if (mat) {
-    f32x16 acc[1];
-    acc[0] = splat(bs[32 * wave + r]);
-    wave_mma_rt<1, KMAX + 1, 1, 1, KMAX + 1>(acc, lds + L_X, lds + L_W1 + 32 * wave * (KMAX + 1), lane, K0p);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4, col0 = 16 * wave;
+  const int K0p = (g.K0 + 15) & ~15, nm1 = K0p >> 4, N3p = (g.N3 + 15) & ~15, nb3 = N3p >> 4;
+  const bool fdx = DX && g.forward_dx;
+  int tile = blockIdx.x;
+  if (tile >= tiles) return;
+  MLP_STAMP(0, 0);
+  int sn = 1;
+  (void)sn;
+  TileIn T;
+  request_x(T, g, tile * ROWS, M, tid, K0p);
+  WFwd W;
+  load_w1_fwd(W, g, col0, j, q);
+  load_w23_fwd(W, g, wave, col0, j, q);
+  WBwd WB;
+  if (DX) load_w_bwd(WB, g, wave, col0, j, q, fdx);
+  float* X = lds + L_X;
+  float* A1 = lds + L_A1;
+  float* A2 = lds + L_A2;
+  for (; tile < tiles; tile += gridDim.x) {
+    const int row0 = tile * ROWS;
+    commit_x(lds, T, tid, K0p);
+    lds_barrier();
+    MLP_STAMP(0, sn++);                                    // inputs (first tile: and the weights of layer 1) have arrived
+    if (tile + (int)gridDim.x < tiles) request_x(T, g, (tile + gridDim.x) * ROWS, M, tid, K0p);
+    // ---- layer 1 (K0 -> 128, ReLU)
+    {
+      f32x4 c = {W.b1, W.b1, W.b1, W.b1};
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[0][i] = fmaxf(acc[0][i], 0.f);
-    store_tile<H + 1>(lds + L_A1, 32 * wave, acc[0], lane);
-  }
-  __syncthreads();
-  // ---- layer 2 (128 -> 128, ReLU)
-  if (mat) {
-    f32x16 acc[1];
-    acc[0] = splat(bs[H + 32 * wave + r]);
-    wave_mma<1, H, H + 1, 1, 1, H + 1>(acc, lds + L_A1, lds + L_W2 + 32 * wave * (H + 1), lane);
+      for (int m = 0; m < NBX; ++m)
+        if (m < nm1) c = mma4(c, lds4(X + j * LDX + 16 * m + 4 * q), W.w1[m]);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[0][i] = fmaxf(acc[0][i], 0.f);
-    store_tile<H + 1>(lds + L_A2, 32 * wave, acc[0], lane);
-  }
-  __syncthreads();
-  // ---- layer 3 (128 -> N3 <= 32, act3): one 16x16 block per wave, straight to global memory
-  if (mat) {
-    const int rb = wave & 1, cb = wave >> 1, j = lane & 15, q = lane >> 4;
-    const f32x4 c = wave_mma16<H, H + 1, 1, 1, H + 1>(lds + L_A2 + 16 * rb * (H + 1), lds + L_W3 + 16 * cb * (H + 1), lane,
-                                                     bs[2 * H + 16 * cb + j]);
-    const int col = 16 * cb + j;
+      for (int e = 0; e < 4; ++e) A1[(4 * q + e) * LDA + col0 + j] = fmaxf(c[e], 0.f);
+    }
+    lds_barrier();
+    MLP_STAMP(0, sn++);
+    // ---- layer 2 (128 -> 128, ReLU)
+    {
+      f32x4 c = {W.b2, W.b2, W.b2, W.b2};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int row = row0 + 16 * rb + 4 * q + e;
-      if (row < M && col < g.N3) {
-        const float v = act_apply(c[e], g.act3);
+      for (int m = 0; m < H / 16; ++m) c = mma4(c, lds4(A1 + j * LDA + 16 * m + 4 * q), W.w2[m]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) A2[(4 * q + e) * LDA + col0 + j] = fmaxf(c[e], 0.f);
+    }
+    lds_barrier();
+    MLP_STAMP(0, sn++);
+    // ---- layer 3 (128 -> N3 <= 32, act3): every wave reduces over its 16 hidden units, the partial blocks meet in LDS
+    {
+      const float4 a = lds4(A2 + j * LDA + col0 + 4 * q);
+#pragma unroll
+      for (int c = 0; c < NMAX / 16; ++c)
+        if (c < nb3) {
+          const f32x4 p = mma4(zero4(), a, W.w3[c]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) lds[L_P + ((wave * (NMAX / 16) + c) * 16 + 4 * q + e) * LDP + j] = p[e];
+        }
+    }
+    if (g.h1 != nullptr && !fdx) {                         // the hidden activations for the backward call, 16 bytes per thread
+      const int rr = tid >> 5, c4 = (tid & 31) * 4;
+      if (row0 + rr < M) {
+        *reinterpret_cast<float4*>(g.h1 + (long)(row0 + rr) * H + c4) = lds4(A1 + rr * LDA + c4);
+        *reinterpret_cast<float4*>(g.h2 + (long)(row0 + rr) * H + c4) = lds4(A2 + rr * LDA + c4);
+      }
+    }
+    lds_barrier();
+    MLP_STAMP(0, sn++);
+    for (int o = tid; o < ROWS * N3p; o += NT) {
+      const int rr = o / N3p, col = o - rr * N3p, row = row0 + rr;
+      float d3 = 0.f;
+      if (col < g.N3 && row < M) {
+        const float v = act_apply(sum_partials(lds, NMAX / 16, rr, col) + g.b3[col], g.act3);
         g.y[(long)row * g.ldy + col] = v;
         if (g.smooth_eps != nullptr) {      // target-policy smoothing of the same value, as td3_smooth_action_kernel
           float n = 0.2f * g.smooth_eps[(long)row * g.N3 + col];
           n = fminf(fmaxf(n, -0.5f), 0.5f);
           g.y2[(long)row * g.ldy2 + col] = fminf(fmaxf(v + n, -1.f), 1.f);
         }
+        d3 = g.dy_const;
+        if (g.act3 != HHRL_ACT_NONE) d3 *= act_grad_from_output(v, g.act3);
+      }
+      if (fdx) lds[L_D3 + rr * LDD + col] = d3;
+    }
+    lds_barrier();
+    MLP_STAMP(0, sn++);
+    if (DX) {
+      if (fdx) {
+        // the input gradient for dL/dy = dy_const on every row (the policy step's d(-mean Q)/d(action)): the tile's
+        // activations are in LDS already; the hidden activations are overwritten by their gradients
+        GradAcc none;
+        tile_backward(lds, g, WB, none, false, true, row0, M, tid, nm1, nb3);
       }
     }
   }
-  if (g.forward_dx) {
-    // ---- the input gradient for dL/dy = dy_const on every row, in the same launch (the policy step's d(-mean Q)/d(action):
-    //      the network's weights and activations are in LDS already).  Same products as the backward kernel without the
-    //      parameter gradients; the hidden activations are overwritten by their gradients and not written to memory.
-    float* D3 = lds + L_Y;
-    __syncthreads();                                   // layer 3 has read h2
-#pragma unroll
-    for (int u = 0; u < 1024 / NT; ++u) {
-      const int e = u * NT + tid, rr = e >> 5, c = e & 31;
-      float v = 0.f;
-      if (c < g.N3 && row0 + rr < M) {
-        v = g.dy_const;
-        if (g.act3 != HHRL_ACT_NONE) v *= act_grad_from_output(g.y[(long)(row0 + rr) * g.ldy + c], g.act3);
-      }
-      D3[rr * 33 + c] = v;
-    }
-    __syncthreads();
-    f32x16 d[1];
-    if (mat) {                                         // dh2 = (D3 W3) o relu'(h2), column block `wave`, in place
-      d[0] = splat(0.f);
-      wave_mma<1, 32, 33, 1, H + 1, 1>(d, D3, lds + L_W3 + 32 * wave, lane);
-      wave_sync();
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float* p = lds + L_A2 + drow(i, h) * (H + 1) + 32 * wave + r;
-        *p = *p > 0.f ? d[0][i] : 0.f;
-      }
-    }
-    __syncthreads();
-    if (mat) {                                         // dh1 = (dh2 W2) o relu'(h1)
-      d[0] = splat(0.f);
-      wave_mma<1, H, H + 1, 1, H + 1, 1>(d, lds + L_A2, lds + L_W2 + 32 * wave, lane);
-    }
-    __syncthreads();                                   // every wave is done reading dh2 ... (and nobody reads h1 any more)
-    if (mat) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float* p = lds + L_A1 + drow(i, h) * (H + 1) + 32 * wave + r;
-        *p = *p > 0.f ? d[0][i] : 0.f;
-      }
-    }
-    __syncthreads();
-    {                                                  // dx = dh1 W1: 16x16 blocks over the helper waves (or waves 0..3)
-      const int xw = NT == 512 ? wave - 4 : wave;
-      if (xw >= 0) {
-        const int rb = xw & 1, j = lane & 15, q = lane >> 4;
-        for (int cb = xw >> 1; 16 * cb < K0p; cb += 2) {
-          const f32x4 c = wave_mma16<H, H + 1, 1, KMAX + 1, 1>(lds + L_A1 + 16 * rb * (H + 1), lds + L_W1 + 16 * cb, lane, 0.f);
-          const int col = 16 * cb + j;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int row = row0 + 16 * rb + 4 * q + e;
-            if (row < M && col < g.K0) g.dx[(long)row * g.lddx + col] = c[e];
-          }
-        }
-      }
-    }
-    return;
-  }
-  if (g.h1 != nullptr) {
-    store_rows128<NT>(lds + L_A1, g.h1, row0, M, tid);
-    store_rows128<NT>(lds + L_A2, g.h2, row0, M, tid);
-  }
-  (void)h;
 }
 
 // ------------------------------------------------------------------ backward
-// With helper waves (NT == 512) waves 4..7 share the copies and own the bias gradients (thread T_B + column).
-template <int NT>
-__global__ __launch_bounds__(NT, 1) void mlp3_backward_kernel(NetGroup grp, int M) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+__global__ __launch_bounds__(NT, 1) void mlp3_backward_kernel(NetGroup grp, int M, int tiles) {
+  __shared__ __attribute__((aligned(16))) float lds[L_END];
   const Net& g = grp.in[blockIdx.y];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-  const bool mat = wave < 4;                      // this wave takes part in the matrix phases
-  constexpr int T_B = NT == 512 ? 256 : 0;
-  const int bcol = tid - T_B;                     // bias-gradient column of this thread (if in range)
-  const int row0 = blockIdx.x * 32;
-  const int K0 = g.K0, K0p = (K0 + 7) & ~7, N3 = g.N3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4, col0 = 16 * wave;
+  const int K0 = g.K0, K0p = (K0 + 15) & ~15, nm1 = K0p >> 4, N3 = g.N3, N3p = (N3 + 15) & ~15, nb3 = N3p >> 4;
   const bool pg = g.gw1 != nullptr;            // parameter gradients wanted
   const bool want_dx = g.dx != nullptr;
-  float* W1s = lds + L_W1;
-  float* W2s = lds + L_W2;
-  float* W3s = lds + L_W3;
-  float* Xs = lds + L_X;
-  float* A1 = lds + L_A1;     // h1, then its gradient
-  float* A2 = lds + L_A2;     // h2, then its gradient
-  float* D3 = lds + L_Y;      // gradient at the pre-activation of layer 3, columns >= N3 zero
-  {
-    StageW<NT> R;
-    float4 a1[W4Map<32, H, NT>::STEPS], a2[W4Map<32, H, NT>::STEPS];
-    request_w23(R, g, tid);
-    request_rows128<NT>(a1, g.h1, row0, M, tid);
-    request_rows128<NT>(a2, g.h2, row0, M, tid);
-    // gradient at the output through act3
-    float d3[1024 / NT];
+  int tile = blockIdx.x;
+  if (tile >= tiles) return;
+  MLP_STAMP(1, 0);
+  int sn = 1;
+  (void)sn;
+  TileIn T;
+  request_bwd(T, g, tile * ROWS, M, tid, N3p);
+  request_x(T, g, tile * ROWS, M, tid, K0p);
+  WBwd W;
+  load_w_bwd(W, g, wave, col0, j, q, want_dx);
+  GradAcc G;
 #pragma unroll
-    for (int u = 0; u < 1024 / NT; ++u) {
-      const int e = u * NT + tid, rr = e >> 5, c = e & 31;
-      float v = 0.f;
-      if (c < N3 && row0 + rr < M) {
-        v = g.dy ? g.dy[(long)(row0 + rr) * g.lddy + c] : g.dy_const;
-        if (g.act3 != HHRL_ACT_NONE) v *= act_grad_from_output(g.y[(long)(row0 + rr) * g.ldy + c], g.act3);
-      }
-      d3[u] = v;
-    }
-    stage_w1_x<NT>(lds, g, row0, M, tid, want_dx);
-    commit_w23(lds, R, tid);
-    commit_w4<32, H, W4Map<32, H, NT>::STEPS, NT>(A1, H + 1, a1, tid);
-    commit_w4<32, H, W4Map<32, H, NT>::STEPS, NT>(A2, H + 1, a2, tid);
+  for (int c = 0; c < NMAX / 16; ++c) G.w3[c] = zero4();
 #pragma unroll
-    for (int u = 0; u < 1024 / NT; ++u) {
-      const int e = u * NT + tid;
-      D3[(e >> 5) * 33 + (e & 31)] = d3[u];
+  for (int c = 0; c < H / 16; ++c) G.w2[c] = zero4();
+#pragma unroll
+  for (int c = 0; c < NBX; ++c) G.w1[c] = zero4();
+  G.b1 = G.b2 = G.b3 = 0.f;
+  for (; tile < tiles; tile += gridDim.x) {
+    commit_x(lds, T, tid, K0p);
+    commit_bwd(lds, T, tid, N3p);
+    lds_barrier();
+    MLP_STAMP(1, sn++);
+    if (tile + (int)gridDim.x < tiles) {
+      request_bwd(T, g, (tile + gridDim.x) * ROWS, M, tid, N3p);
+      request_x(T, g, (tile + gridDim.x) * ROWS, M, tid, K0p);
     }
+    tile_backward(lds, g, W, G, pg, want_dx, tile * ROWS, M, tid, nm1, nb3);
+    MLP_STAMP(1, sn++);
   }
-  __syncthreads();
-  // ---- layer 3: db3, dW3 [N3][128] += D3^T h2, dh2 = (D3 W3) o relu'(h2) in place (column block `wave`)
-  if (pg && bcol >= 0 && bcol < N3) {
-    float s = 0.f;
-    for (int rr = 0; rr < 32; ++rr) s += D3[rr * 33 + bcol];
-    unsafeAtomicAdd(&g.gb3[bcol], s);
-  }
-  if (mat) {
-    if (pg) {
-      f32x16 acc[1];
-      acc[0] = splat(0.f);
-      wave_mma<1, 32, 1, 33, H + 1, 1>(acc, D3, A2 + 32 * wave, lane);
+  if (!pg) return;
+  // ---- this workgroup's share of the parameter gradients, handed over once
+  if (g.slab != nullptr) {
+    float* sl = g.slab + (long)blockIdx.x * slab_floats(K0, N3);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = drow(i, h);
-        if (row < N3) unsafeAtomicAdd(&g.gw3[row * H + 32 * wave + r], acc[0][i]);
-      }
-    }
-    f32x16 d[1];
-    d[0] = splat(0.f);
-    wave_mma<1, 32, 33, 1, H + 1, 1>(d, D3, W3s + 32 * wave, lane);
-    wave_sync();
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      float* p = A2 + drow(i, h) * (H + 1) + 32 * wave + r;
-      *p = *p > 0.f ? d[0][i] : 0.f;
-    }
-  }
-  __syncthreads();
-  // ---- layer 2: db2, dW2 [128][128] += dh2^T h1 (row tile `wave`), dh1 = (dh2 W2) o relu'(h1) in place
-  {
-    if (pg && bcol >= 0 && bcol < H) {
-      float s = 0.f;
-      for (int rr = 0; rr < 32; ++rr) s += A2[rr * (H + 1) + bcol];
-      unsafeAtomicAdd(&g.gb2[bcol], s);
-    }
-    f32x16 d[1];
-    d[0] = splat(0.f);
-    if (mat) {
-      if (pg) {
-        f32x16 acc[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = splat(0.f);
-        wave_mma<4, 32, 1, H + 1, H + 1, 1>(acc, A2 + 32 * wave, A1, lane);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) unsafeAtomicAdd(&g.gw2[(32 * wave + drow(i, h)) * H + 32 * t + r], acc[t][i]);
-      }
-      wave_mma<1, H, H + 1, 1, H + 1, 1>(d, A2, W2s + 32 * wave, lane);
-    }
-    __syncthreads();                                   // every wave is done reading h1
-    if (mat) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float* p = A1 + drow(i, h) * (H + 1) + 32 * wave + r;
-        *p = *p > 0.f ? d[0][i] : 0.f;
-      }
-    }
-  }
-  __syncthreads();
-  // ---- layer 1: db1, dW1 [128][K0] += dh1^T x (row tile `wave`), dx = dh1 W1 (16x16 blocks)
-  if (pg && bcol >= 0 && bcol < H) {
-    float s = 0.f;
-    for (int rr = 0; rr < 32; ++rr) s += A1[rr * (H + 1) + bcol];
-    unsafeAtomicAdd(&g.gb1[bcol], s);
-  }
-  if (pg && mat) {
-    f32x16 acc[2];
-    acc[0] = splat(0.f);
-    acc[1] = splat(0.f);
-    wave_mma<2, 32, 1, H + 1, KMAX + 1, 1>(acc, A1 + 32 * wave, Xs, lane);     // columns >= K0p read zero padding or junk, dropped below
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int col = 32 * t + r;
-      if (col < K0) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) unsafeAtomicAdd(&g.gw1[(32 * wave + drow(i, h)) * K0 + col], acc[t][i]);
-      }
-    }
-  }
-  if (want_dx) {
-    // 16x16 blocks of dx: over waves 0..3, or over the four helper waves when there are any (they are idle here)
-    const int xw = NT == 512 ? wave - 4 : wave;
-    if (xw >= 0) {
-      const int rb = xw & 1, j = lane & 15, q = lane >> 4;
-      for (int cb = xw >> 1; 16 * cb < K0p; cb += 2) {
-        const f32x4 c = wave_mma16<H, H + 1, 1, KMAX + 1, 1>(A1 + 16 * rb * (H + 1), W1s + 16 * cb, lane, 0.f);
-        const int col = 16 * cb + j;
+    for (int c = 0; c < NMAX / 16; ++c)
+      if (c < nb3) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int row = row0 + 16 * rb + 4 * q + e;
-          if (row < M && col < K0) g.dx[(long)row * g.lddx + col] = c[e];
+          const int n = 16 * c + 4 * q + e;
+          if (n < N3) sl[slab_w3(K0, N3) + n * H + col0 + j] = G.w3[c][e];
         }
       }
+#pragma unroll
+    for (int c = 0; c < H / 16; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sl[slab_w2(K0, N3) + (col0 + 4 * q + e) * H + 16 * c + j] = G.w2[c][e];
+#pragma unroll
+    for (int c = 0; c < NBX; ++c)
+      if (c < nm1 && 16 * c + j < K0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sl[slab_w1(K0, N3) + (col0 + 4 * q + e) * K0 + 16 * c + j] = G.w1[c][e];
+      }
+    if (tid < H) {
+      sl[slab_b1(K0, N3) + tid] = G.b1;
+      sl[slab_b2(K0, N3) + tid] = G.b2;
     }
+    if (tid < N3) sl[slab_b3(K0, N3) + tid] = G.b3;
+    return;
+  }
+#pragma unroll
+  for (int c = 0; c < NMAX / 16; ++c)
+    if (c < nb3) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = 16 * c + 4 * q + e;
+        if (n < N3) unsafeAtomicAdd(&g.gw3[n * H + col0 + j], G.w3[c][e]);
+      }
+    }
+#pragma unroll
+  for (int c = 0; c < H / 16; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) unsafeAtomicAdd(&g.gw2[(col0 + 4 * q + e) * H + 16 * c + j], G.w2[c][e]);
+#pragma unroll
+  for (int c = 0; c < NBX; ++c)
+    if (c < nm1 && 16 * c + j < K0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) unsafeAtomicAdd(&g.gw1[(long)(col0 + 4 * q + e) * K0 + 16 * c + j], G.w1[c][e]);
+    }
+  if (tid < H) {
+    unsafeAtomicAdd(&g.gb1[tid], G.b1);
+    unsafeAtomicAdd(&g.gb2[tid], G.b2);
+  }
+  if (tid < N3) unsafeAtomicAdd(&g.gb3[tid], G.b3);
+}
+
+// Sum of the slab rows in workgroup order, added to the gradient buffers.  A workgroup owns 32 consecutive
+// parameters; its eight groups of 32 threads each sum every eighth row (eight loads in flight per thread),
+// the eight sums meet in LDS and are added in group order.  blockIdx.y = network.
+__global__ __launch_bounds__(256) void mlp3_slab_reduce_kernel(NetGroup grp, int rows) {
+  __shared__ float part[8][33];
+  const Net& g = grp.in[blockIdx.y];
+  if (g.slab == nullptr || g.gw1 == nullptr) return;
+  const int P = slab_floats(g.K0, g.N3);
+  const int c = threadIdx.x & 31, grp8 = threadIdx.x >> 5, e = blockIdx.x * 32 + c;
+  float s = 0.f;
+  if (e < P) {
+    const float* p = g.slab + e;
+    int r = grp8;
+    for (; r + 56 < rows; r += 64) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(long)(r + 8 * u) * P];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; r < rows; r += 8) s += p[(long)r * P];
+  }
+  part[grp8][c] = s;
+  __syncthreads();
+  if (grp8 == 0 && e < P) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += part[k][c];
+    const int K0 = g.K0, N3 = g.N3;
+    float* dst = e < slab_b1(K0, N3)   ? g.gw1 + e
+                 : e < slab_w2(K0, N3) ? g.gb1 + (e - slab_b1(K0, N3))
+                 : e < slab_b2(K0, N3) ? g.gw2 + (e - slab_w2(K0, N3))
+                 : e < slab_w3(K0, N3) ? g.gb2 + (e - slab_b2(K0, N3))
+                 : e < slab_b3(K0, N3) ? g.gw3 + (e - slab_w3(K0, N3))
+                                       : g.gb3 + (e - slab_b3(K0, N3));
+    *dst += t;
   }
 }
 
-// Threads per workgroup: 512 (four helper waves) unless HHRL_MLP_THREADS=256 asks for the plain form.
-static int g_threads = 0;
-static int set_attrs() {
-  const void* fns[] = {reinterpret_cast<const void*>(mlp3_forward_kernel<256>), reinterpret_cast<const void*>(mlp3_forward_kernel<512>),
-                       reinterpret_cast<const void*>(mlp3_backward_kernel<256>), reinterpret_cast<const void*>(mlp3_backward_kernel<512>)};
-  for (int i = 0; i < 4; ++i) HHRL_TRY(ensure_dyn_lds(fns[i], L_END * 4, "mlp3"));
-  if (g_threads == 0) {
-    const char* e = getenv("HHRL_MLP_THREADS");
-    g_threads = (e && atoi(e) == 256) ? 256 : 512;
+// Workgroups per launch: as many as fill the chip once (256 CUs, one workgroup each), shared among the
+// networks of the group; a workgroup loops over its tiles.  HHRL_MLP3_WGS=n sets another total (for sweeps).
+static int grid_x(int tiles, int n) {
+  static int total = 0;
+  if (total == 0) {
+    const char* e = getenv("HHRL_MLP3_WGS");
+    total = (e && atoi(e) > 0) ? atoi(e) : 256;
   }
-  return HHRL_OK;
+  int per = total / n;
+  if (per < 1) per = 1;
+  return tiles < per ? tiles : per;
 }
+
+// Fewest workgroups per network from which the slab hand-over is used (when the caller gave a slab)
+constexpr int kSlabMinRows = 16;
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -457,6 +603,7 @@ static int fill_group(NetGroup& grp, const hhrl_mlp3_desc* d, int n, int M, bool
     g.smooth_eps = backward ? nullptr : s.smooth_eps; g.y2 = s.y2; g.ldy2 = s.ldy2;
     g.ldx = s.ldx; g.ldy = s.ldy; g.lddy = s.lddy; g.lddx = s.lddx; g.K0 = s.K0; g.N3 = s.N3; g.act3 = s.act3;
     g.forward_dx = backward ? 0 : s.forward_dx;
+    g.slab = nullptr;
   }
   return HHRL_OK;
 }
@@ -473,34 +620,68 @@ int hhrl_mlp3_supported(int K0, int H1, int H2, int N3) {
   return K0 >= 1 && K0 <= KMAX && H1 == H && H2 == H && N3 >= 1 && N3 <= NMAX;
 }
 
+long hhrl_mlp3_slab_floats(int K0, int N3, int M) {
+  if (!hhrl_mlp3_supported(K0, H, H, N3) || M <= 0) return 0;
+  const int tiles = ceil_div(M, ROWS), gx = grid_x(tiles, 1);     // a group of one has the most workgroups per network
+  return gx >= kSlabMinRows ? (long)gx * slab_floats(K0, N3) : 0;
+}
+
 int hhrl_mlp3_forward_group(const hhrl_mlp3_desc* d, int n, int M, void* stream) {
   NetGroup grp;
   HHRL_TRY(fill_group(grp, d, n, M, false));
-  HHRL_TRY(set_attrs());
   hipStream_t st = as_stream(stream);
   double flops = 0.0;
-  for (int i = 0; i < n; ++i) flops += 2.0 * M * ((double)d[i].K0 * H + (double)H * H + (double)H * d[i].N3);
+  bool dx = false;
+  for (int i = 0; i < n; ++i) {
+    flops += 2.0 * M * ((double)d[i].K0 * H + (double)H * H + (double)H * d[i].N3);
+    dx = dx || d[i].forward_dx != 0;
+  }
+  const int tiles = ceil_div(M, ROWS);
   ProfScope ps("mlp3_forward_kernel", st, flops, 0.0);
-  if (g_threads == 512)
-    hipLaunchKernelGGL(mlp3_forward_kernel<512>, dim3(ceil_div(M, 32), n), dim3(512), L_END * 4, st, grp, M);
+  if (dx)
+    hipLaunchKernelGGL(mlp3_forward_kernel<true>, dim3(grid_x(tiles, n), n), dim3(NT), 0, st, grp, M, tiles);
   else
-    hipLaunchKernelGGL(mlp3_forward_kernel<256>, dim3(ceil_div(M, 32), n), dim3(256), L_END * 4, st, grp, M);
+    hipLaunchKernelGGL(mlp3_forward_kernel<false>, dim3(grid_x(tiles, n), n), dim3(NT), 0, st, grp, M, tiles);
   return launch_status("mlp3_forward_kernel");
 }
 
 int hhrl_mlp3_backward_group(const hhrl_mlp3_desc* d, int n, int M, void* stream) {
   NetGroup grp;
   HHRL_TRY(fill_group(grp, d, n, M, true));
-  HHRL_TRY(set_attrs());
   hipStream_t st = as_stream(stream);
   double flops = 0.0;
   for (int i = 0; i < n; ++i) flops += 4.0 * M * ((double)d[i].K0 * H + (double)H * H + (double)H * d[i].N3);
-  ProfScope ps("mlp3_backward_kernel", st, flops, 0.0);
-  if (g_threads == 512)
-    hipLaunchKernelGGL(mlp3_backward_kernel<512>, dim3(ceil_div(M, 32), n), dim3(512), L_END * 4, st, grp, M);
-  else
-    hipLaunchKernelGGL(mlp3_backward_kernel<256>, dim3(ceil_div(M, 32), n), dim3(256), L_END * 4, st, grp, M);
-  return launch_status("mlp3_backward_kernel");
+  const int tiles = ceil_div(M, ROWS), gx = grid_x(tiles, n);
+  bool slabs = false;
+  int pmax = 0;
+  for (int i = 0; i < n; ++i) {
+    const int P = slab_floats(d[i].K0, d[i].N3);
+    if (d[i].gslab != nullptr && d[i].gw1 != nullptr && gx >= kSlabMinRows) {
+      HHRL_REQUIRE(d[i].gslab_floats >= (long)gx * P, "mlp3_backward: network %d: slab of %ld floats, %ld needed (hhrl_mlp3_slab_floats)",
+                   i, d[i].gslab_floats, (long)gx * P);
+      grp.in[i].slab = d[i].gslab;
+      slabs = true;
+      pmax = P > pmax ? P : pmax;
+    }
+  }
+  {
+    ProfScope ps("mlp3_backward_kernel", st, flops, 0.0);
+    hipLaunchKernelGGL(mlp3_backward_kernel, dim3(gx, n), dim3(NT), 0, st, grp, M, tiles);
+    HHRL_TRY(launch_status("mlp3_backward_kernel"));
+  }
+  if (slabs) {
+    ProfScope ps("mlp3_slab_reduce_kernel", st, 0.0, 4.0 * n * (double)pmax * (gx + 2));
+    hipLaunchKernelGGL(mlp3_slab_reduce_kernel, dim3(ceil_div(pmax, 32), n), dim3(256), 0, st, grp, gx);
+    HHRL_TRY(launch_status("mlp3_slab_reduce_kernel"));
+  }
+  return HHRL_OK;
 }
+
+#ifdef HHRL_STAMPS
+// diagnostic builds only: copies the recorded clocks (forward, backward: 64 stamps each) to the host
+int hhrl_debug_mlp_stamps(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(hhrl::mf::g_mlp_stamps), sizeof(long long) * 2 * 64) == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // extern "C"

@@ -85,6 +85,15 @@ class Mlp3:
     def __init__(self, l1: Lin, l2: Lin, l3: Lin):
         self.l = (l1, l2, l3)
         self.K0, self.N3, self.act3 = l1.K, l3.N, l3.act
+        self._slabs = {}          # rows M -> workspace for the slab hand-over of the parameter gradients (large M only)
+
+    def slab(self, M: int, device) -> Optional[torch.Tensor]:
+        """Workspace that lets the backward call sum its workgroups' parameter gradients in a fixed order
+        instead of adding them with atomics (None where the atomics path serves M rows)."""
+        if M not in self._slabs:
+            n = _lib.load().hhrl_mlp3_slab_floats(self.K0, self.N3, M)
+            self._slabs[M] = dev_empty(n, device=device) if n > 0 else None
+        return self._slabs[M]
 
     @staticmethod
     def supported(l1: Lin, l2: Lin, l3: Lin) -> bool:
@@ -99,11 +108,14 @@ class Mlp3:
         d.N3, d.act3 = self.N3, self.act3
         d.h1, d.h2, d.y, d.ldy = h1, h2, y, ldy
 
-    def grads(self, d, dy: Optional[int], lddy: int, dy_const: float, param_grads: bool, dx: Optional[int], lddx: int) -> None:
+    def grads(self, d, dy: Optional[int], lddy: int, dy_const: float, param_grads: bool, dx: Optional[int], lddx: int,
+              slab: Optional[torch.Tensor] = None) -> None:
         l1, l2, l3 = self.l
         d.dy, d.lddy, d.dy_const = dy, lddy, dy_const
         if param_grads:
             d.gw1, d.gb1, d.gw2, d.gb2, d.gw3, d.gb3 = l1.gw, l1.gb, l2.gw, l2.gb, l3.gw, l3.gb
+            if slab is not None:
+                d.gslab, d.gslab_floats = slab.data_ptr(), slab.numel()
         d.dx, d.lddx = dx, lddx
 
 

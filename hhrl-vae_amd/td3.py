@@ -154,7 +154,7 @@ class ActorNet:
         if self.mlp3 is not None:
             d = ops.mlp3_descs(1)
             self.fused_desc(d[0], B, out, ld_out)
-            self.mlp3.grads(d[0], d_out, ld_dout, 0.0, True, None, 0)
+            self.mlp3.grads(d[0], d_out, ld_dout, 0.0, True, None, 0, self.mlp3.slab(B, self.dev))
             ops.mlp3_backward_group(d, B)
             return
         self.l3.bwd(P(w.h2), self.h[1], out, ld_out, d_out, ld_dout, P(w.d_h2), self.h[1], B)
@@ -345,10 +345,12 @@ class CriticNet:
         if self.mlp3 is not None and not (both_heads and need_dxu):
             d = ops.mlp3_descs(2 if both_heads else 1)
             self.mlp3[0].desc(d[0], P(w.xu_pi if policy_input else w.xu), self.D, P(w.q1), 1, P(w.a1), P(w.a2))
-            self.mlp3[0].grads(d[0], None if dq_const is not None else P(w.d_q1), 1, dq_const or 0.0, param_grads, dxu, self.D)
+            self.mlp3[0].grads(d[0], None if dq_const is not None else P(w.d_q1), 1, dq_const or 0.0, param_grads, dxu, self.D,
+                               self.mlp3[0].slab(B, self.dev) if param_grads else None)
             if both_heads:
                 self.mlp3[1].desc(d[1], P(w.xu), self.D, P(w.q2), 1, P(w.b1), P(w.b2))
-                self.mlp3[1].grads(d[1], P(w.d_q2), 1, 0.0, param_grads, None, 0)
+                self.mlp3[1].grads(d[1], P(w.d_q2), 1, 0.0, param_grads, None, 0,
+                                   self.mlp3[1].slab(B, self.dev) if param_grads else None)
             ops.mlp3_backward_group(d, B)
             return
         d_q1 = P(w.d_q1)

@@ -230,7 +230,9 @@ int hhrl_td3_target_mse(const float* q1t, const float* q2t, const float* r, int 
  * Forward writes y and, when h1/h2 are given, the two hidden activations [M,128] that the backward
  * call reads.  Backward: dy is dL/dy (null: every element equals dy_const, the gradient of a mean);
  * the six gradient pointers are all given (gradients are ADDED) or all null (input gradient only);
- * dx, when given, receives dL/dx. */
+ * dx, when given, receives dL/dx.
+ * Weights stay in registers (a wave owns 16 output columns of each hidden layer), rows go through LDS in tiles
+ * of 16; a launch has at most 256 workgroups, each looping over its tiles. */
 #define HHRL_MLP3_GROUP_MAX 8
 typedef struct {
   const float* x; int ldx; int K0;
@@ -247,8 +249,13 @@ typedef struct {
   /* forward only, optional: nonzero = the launch also writes dx, the input gradient for dL/dy = dy_const on
    * every row (d(-mean Q1)/d(s, a) of a policy step, algorithm.py:1353-1357), and then does not save h1 / h2 */
   int forward_dx;
+  /* backward only, optional: workspace of gslab_floats >= hhrl_mlp3_slab_floats(K0, N3, M) floats.  With it, and with
+   * enough rows, the workgroups hand their parameter gradients over as slab rows that a second launch sums in a
+   * fixed order (same bits on every run) instead of adding them with float atomics. */
+  float* gslab; long gslab_floats;
 } hhrl_mlp3_desc;
 int hhrl_mlp3_supported(int K0, int H1, int H2, int N3);
+long hhrl_mlp3_slab_floats(int K0, int N3, int M);   /* 0: the atomics path serves this M */
 int hhrl_mlp3_forward_group(const hhrl_mlp3_desc* nets, int n, int M, void* stream);
 int hhrl_mlp3_backward_group(const hhrl_mlp3_desc* nets, int n, int M, void* stream);
 

@@ -1,7 +1,7 @@
 """The data-parallel code path on a real GPU with a one-rank RCCL group: the
 process group, the flat gradient(+loss) all-reduce and the separate Adam
-launch must reproduce the single-device step bit for bit (a one-rank SUM is
-the identity).  The two-rank arithmetic is covered on CPU by test_dist_gloo."""
+launch must reproduce the single-device step (a one-rank SUM is the identity):
+bit for bit for the VAE, apart from the order of float atomics for the TD3 updates.  The two-rank arithmetic is covered on CPU by test_dist_gloo."""
 import os
 
 import numpy as np
@@ -61,9 +61,11 @@ def test_td3_one_rank_group_matches_single_device(group):
         noise = [rs.standard_normal((a.batch_size, d)).astype(np.float32) for d in a.fam.a_dims]
         a.learn(indices=idx, noise=noise)
         b.learn(indices=idx, noise=noise)
+    # equal apart from the order in which the four workgroups of a network add their weight gradients (float atomics)
+    from test_gpu_kernels import scaled_close
     for (na, sa), (nb, sb) in zip(a.state_dicts().items(), b.state_dicts().items()):
         for k in sa:
-            assert torch.equal(sa[k], sb[k]), (na, k)
+            scaled_close(na + "/" + k, sb[k].cpu().numpy(), sa[k].cpu().numpy(), rtol=1e-5, atol_rel=1e-6)
 
 
 def test_multi_actor_group_update_draws_one_order(group):
@@ -108,9 +110,10 @@ def _pair(make, n_rows, seed=2):
 def test_worker_reference_widths_every_chain_replayed_under_rccl(group, in_graph):
     """WorkerTD3 at the reference's widths under the one-rank RCCL group for ten updates: both launch chains
     (plain and policy step) pass their eager runs, are captured -- as `graph, all-reduce, graph, ...` segments, or
-    (in_graph) as one graph that holds the collectives -- and are replayed several times; bit-equal to the
-    single-device learner (two workgroups per network at batch 64: a sum of two float atomics is order-free)."""
+    (in_graph) as one graph that holds the collectives -- and are replayed several times; equal to the
+    single-device learner apart from the order of the weight-gradient atomics (four workgroups per network)."""
     from hhrl_vae_amd.algorithm import WorkerTD3
+    from test_gpu_kernels import scaled_close
     cfg = gen.cav_cfg(cap=256)
 
     def make(g):
@@ -129,12 +132,10 @@ def test_worker_reference_widths_every_chain_replayed_under_rccl(group, in_graph
     assert len(forms) == 2 and set(forms.values()) == {"graph"}, forms
     if not in_graph:
         assert sorted(len(s) for s in b._seg_graphs.values()) == [2, 3]       # critic | critic, actor | rest
-    for (na, sa), (nb, sb) in zip(a.state_dicts().items(), b.state_dicts().items()):
-        for k in sa:
-            assert torch.equal(sa[k], sb[k]), (na, k)
-    for (na, sa), (nb, sb) in zip(a.target_state_dicts().items(), b.target_state_dicts().items()):
-        for k in sa:
-            assert torch.equal(sa[k], sb[k]), (na, k)
+    for get in ("state_dicts", "target_state_dicts"):
+        for (na, sa), (nb, sb) in zip(getattr(a, get)().items(), getattr(b, get)().items()):
+            for k in sa:
+                scaled_close("%s/%s/%s" % (get, na, k), sb[k].cpu().numpy(), sa[k].cpu().numpy(), rtol=1e-5, atol_rel=1e-6)
 
 
 @pytest.mark.parametrize("in_graph", [False, True])

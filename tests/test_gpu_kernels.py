@@ -493,7 +493,8 @@ def test_copy2d_group(env):
     assert lib.hhrl_copy2d_group(arr, 0, M, None) != 0
 
 
-@pytest.mark.parametrize("M,K0,N3,act3", [(64, 17, 1, 2), (64, 18, 1, 0), (37, 64, 32, 3), (4096, 11, 4, 2), (1, 1, 1, 0)])
+@pytest.mark.parametrize("M,K0,N3,act3", [(64, 17, 1, 2), (64, 18, 1, 0), (37, 64, 32, 3), (4096, 11, 4, 2), (1, 1, 1, 0),
+                                            (1000, 33, 17, 3), (20000, 18, 1, 0)])
 def test_mlp3_fused_matches_torch(env, M, K0, N3, act3):
     """hhrl_mlp3_forward_group / _backward_group (two networks side by side) against torch autograd:
     parameter gradients, input gradient, and the constant-upstream-gradient form."""
@@ -528,7 +529,12 @@ def test_mlp3_fused_matches_torch(env, M, K0, N3, act3):
         d.dy, d.lddy, d.dy_const = (None, 0, -0.25) if const else (dyd.data_ptr(), N3, 0.0)
         d.gw1, d.gb1, d.gw2, d.gb2, d.gw3, d.gb3 = [t.data_ptr() for t in gd]
         d.dx, d.lddx = dxd.data_ptr(), K0 + 1
-        keep.append((xd, dyd, wd, gd, h1, h2, yd, dxd))
+        n_slab = lib.hhrl_mlp3_slab_floats(K0, N3, M)
+        assert (n_slab > 0) == (M >= 256)
+        slab = torch.full((max(n_slab, 1),), float("nan"), device=dev)    # every slab entry read is one the kernel wrote
+        if n_slab:
+            d.gslab, d.gslab_floats = slab.data_ptr(), n_slab
+        keep.append((xd, dyd, wd, gd, h1, h2, yd, dxd, slab))
         refs.append((y.detach(), xt.grad, [w.grad for w in wt]))
     st = L.stream_ptr()
     # network 0 also hands its output through the target-policy smoothing, into a wider row
@@ -542,13 +548,30 @@ def test_mlp3_fused_matches_torch(env, M, K0, N3, act3):
     assert torch.equal(sm_out, sm_want)
     for i in range(n):
         y, dx, gws = refs[i]
-        xd, dyd, wd, gd, h1, h2, yd, dxd = keep[i]
+        xd, dyd, wd, gd, h1, h2, yd, dxd, _ = keep[i]
         scaled_close("y[%d]" % i, yd[:, :N3].cpu().numpy(), y.numpy(), atol_rel=5e-6)
         assert torch.all(yd[:, N3:] == 7.0), "forward wrote outside its column slice"
         scaled_close("dx[%d]" % i, dxd[:, :K0].cpu().numpy(), dx.numpy(), atol_rel=1e-5)
         assert torch.all(dxd[:, K0:] == 0.0)
         for k, (got, want) in enumerate(zip(gd, gws)):
             scaled_close("grad[%d][%d]" % (i, k), got.cpu().numpy(), want.numpy(), atol_rel=1e-5)
+    if M >= 256:
+        # parameter gradients handed over through slabs are summed in a fixed order: the same bits on every run,
+        # and close to what the atomics path (no slab given) adds up
+        first = [[t.clone() for t in keep[i][3]] for i in range(n)]
+        for i in range(n):
+            for t in keep[i][3]:
+                t.zero_()
+        L.check(lib.hhrl_mlp3_backward_group(descs, n, M, st))
+        for i in range(n):
+            assert all(torch.equal(a, b) for a, b in zip(first[i], keep[i][3])), "slab path is not reproducible"
+            for t in keep[i][3]:
+                t.zero_()
+            descs[i].gslab, descs[i].gslab_floats = None, 0
+        L.check(lib.hhrl_mlp3_backward_group(descs, n, M, st))
+        for i in range(n):
+            for k, (got, want) in enumerate(zip(keep[i][3], refs[i][2])):
+                scaled_close("atomics grad[%d][%d]" % (i, k), got.cpu().numpy(), want.numpy(), atol_rel=1e-5)
     # forward and input gradient for a constant dL/dy in ONE launch (network 1): same y and dx as the two calls above
     d = descs[1]
     y_two, dx_two = keep[1][6].clone(), keep[1][7].clone()

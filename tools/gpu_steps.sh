@@ -5,6 +5,7 @@
 #   step <seconds> <log> <command...>
 step() {
   local limit=$1 log=$2; shift 2
+  mkdir -p "$(dirname "$log")"
   echo "== $(date +%H:%M:%S) $* (limit ${limit}s) -> $log"
   timeout -k 10 "$limit" "$@" > "$log" 2>&1
   local rc=$?
