@@ -96,6 +96,8 @@ inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 // pair of HIP events recorded on the launch stream and notes the algorithmic
 // work (flops, bytes) of that launch; hhrl_prof_report() aggregates by name.
 bool prof_on();
+bool prof_shapes();                          // profiling on and HHRL_PROF_SHAPES=1: product launches are reported per shape
+const char* prof_intern(const char* name);   // a copy of `name` that lives as long as the process
 struct ProfScope {
   // own_launch: the events are not recorded around the launch but handed to it (launch_timed below), so that
   // they carry the dispatch's own begin and end timestamps, the interval a kernel trace reports

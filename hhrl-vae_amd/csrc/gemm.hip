@@ -339,6 +339,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_small_group_kernel(GemmGroup grp
   gemm_small_body<NW>(g, blockIdx.x, blockIdx.y, bz);
 }
 
+
 // The same for products with FEW output tiles (a batch-64 layer of 400 outputs is 26 tiles of 32 x 32: a tenth of
 // the CUs, each with 8 x 32 matrix instructions of 64 cycles in a row): 16 x 16 output tiles on
 // v_mfma_f32_16x16x4_f32, four times the workgroups, a quarter of the matrix-pipe time and half the operand bytes
@@ -550,6 +551,15 @@ bool gemm_is_small(const GemmArgs& g) { return (long)ceil_div(g.M, 32) * ceil_di
 
 static int gemm_one(GemmArgs g, hipStream_t st);
 
+// "<kernel>[n x MxNxK aK|aI bK|bJ mode m]" of a launch's first product while shapes are being profiled, else `kernel`
+static const char* shape_name(const char* kernel, const GemmArgs& g, int n, int splits) {
+  if (!prof_shapes()) return kernel;
+  char buf[160];
+  snprintf(buf, sizeof(buf), "%s[%dx%dx%dx%d,%s%s,mode%d,splits%d%s]", kernel, n, g.M, g.N, g.K, g.a_kcontig ? "aK" : "aI",
+           g.b_kcontig ? "bK" : "bJ", g.mode, splits, g.Y ? ",mask" : "");
+  return prof_intern(buf);
+}
+
 int gemm_group(const GemmArgs* gs, int n, hipStream_t st) {
   if (n <= 0) return HHRL_OK;
   // the grouped kernel serves latency-bound sizes; anything larger goes through the single-product path
@@ -586,12 +596,12 @@ int gemm_group(const GemmArgs* gs, int n, hipStream_t st) {
   for (int i = 0; i < n; ++i) tiles32 += (long)ceil_div(gs[i].M, 32) * ceil_div(gs[i].N, 32) * (gs[i].mode == 2 ? grp.splits : 1);
   if (tiny_wanted(tiles32)) {
     dim3 grid(ceil_div(max_n, 16), ceil_div(max_m, 16), n * grp.splits);
-    ProfScope ps("gemm_tiny_group_kernel", st, flops, bytes);
+    ProfScope ps(shape_name("gemm_tiny_group_kernel", gs[0], n, grp.splits), st, flops, bytes);
     hipLaunchKernelGGL(gemm_tiny_group_kernel, grid, dim3(512), 0, st, grp);
     return launch_status("gemm_tiny_group_kernel");
   }
   dim3 grid(ceil_div(max_n, 32), ceil_div(max_m, 32), n * grp.splits);
-  ProfScope ps("gemm_small_group_kernel", st, flops, bytes);
+  ProfScope ps(shape_name("gemm_small_group_kernel", gs[0], n, grp.splits), st, flops, bytes);
   if (small_waves() == 8) hipLaunchKernelGGL(gemm_small_group_kernel<8>, grid, dim3(512), 0, st, grp);
   else hipLaunchKernelGGL(gemm_small_group_kernel<4>, grid, dim3(256), 0, st, grp);
   return launch_status("gemm_small_group_kernel");
@@ -621,12 +631,12 @@ static int gemm_one(GemmArgs g, hipStream_t st) {
     }
     if (tiny_wanted(tiles32 * gz)) {
       dim3 grid(ceil_div(N, 16), ceil_div(M, 16), gz);
-      ProfScope ps("gemm_tiny_kernel", st, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + (double)M * N));
+      ProfScope ps(shape_name("gemm_tiny_kernel", g, 1, gz), st, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + (double)M * N));
       hipLaunchKernelGGL(gemm_tiny_kernel, grid, dim3(512), 0, st, g);
       return launch_status("gemm_tiny_kernel");
     }
     dim3 grid(ceil_div(N, 32), ceil_div(M, 32), gz);
-    ProfScope ps("gemm_small_kernel", st, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + (double)M * N));
+    ProfScope ps(shape_name("gemm_small_kernel", g, 1, gz), st, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + (double)M * N));
     if (small_waves() == 8) hipLaunchKernelGGL(gemm_small_kernel<8>, grid, dim3(512), 0, st, g);
     else hipLaunchKernelGGL(gemm_small_kernel<4>, grid, dim3(256), 0, st, g);
     return launch_status("gemm_small_kernel");

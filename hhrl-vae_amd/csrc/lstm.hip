@@ -23,8 +23,20 @@ static inline long align64(long n) { return (n + 63) & ~63L; }
 
 struct LstmWs {
   float *x_tm, *gates, *hbuf, *cbuf, *gates_r, *c_r, *cat, *dgates, *dgates_r, *dcat, *dc, *dh;
+  float* dwslab;          // [win_splits][4H*H + 4H*o + 4H] partial window weight gradients (long windows x batches only)
   long total;
 };
+
+// The window's weight gradients as a reduction over the rows (t, b) split into this many slabs, one workgroup row
+// each (lstm_window_dw_kernel); 0 = the grouped small-product kernels serve the size.
+constexpr int kWinKc = 32;                    // rows (t, b) per staged chunk
+constexpr long kWinMinRows = 2048;
+static int win_splits(long B, long T, long o, long H) {
+  const long K = T * B;
+  if (H != 128 || o > 32 || K < kWinMinRows) return 0;
+  const long s = (K + 4 * kWinKc - 1) / (4 * kWinKc);      // at least four chunks per slab
+  return (int)(s < 32 ? s : 32);
+}
 
 static LstmWs carve(float* ws, long B, long T, long o, long H) {
   LstmWs w;
@@ -42,6 +54,7 @@ static LstmWs carve(float* ws, long B, long T, long o, long H) {
   w.dcat = take(B * 2 * H);
   w.dc = take(B * H);
   w.dh = take(B * H);
+  w.dwslab = take((long)win_splits(B, T, o, H) * (4 * H * H + 4 * H * o + 4 * H));
   w.total = off;
   return w;
 }
@@ -874,6 +887,124 @@ using namespace hhrl;
 
 extern "C" {
 
+
+// ---- weight gradients of a whole window (H = 128, o <= 32): dW_hh [512][128] = dgates^T hprev, dW_ih [512][o] = dgates^T x,
+// bias gradient = column sums of dgates, reductions over the T*B rows (t, b).  The output is small and the reduction
+// long, so a workgroup takes 128 gate rows (blockIdx.x) x ALL 128 + o columns for one slab of the reduction range
+// (blockIdx.y): its four waves own 32 gate rows each with five 32 x 32 accumulators (four column blocks of W_hh, one
+// of W_ih), the operands of a chunk of 32 rows (t, b) are staged once per workgroup through LDS (two buffers, the next
+// chunk's loads in flight during the products) and every staged dgates element feeds 160 products: 33 FLOP per byte
+// fetched, against 8 for 32 x 32 output tiles.  The slabs' partial results go to the workspace and are summed in slab
+// order by lstm_window_dw_reduce_kernel (the same bits on every run; no atomics).
+struct WinDwInst { const float *dgates, *hprev, *x; float *slab, *g_ih, *g_hh, *g_bih, *g_bhh; int o; };
+struct WinDwGroup { WinDwInst in[kMaxInst]; };
+constexpr int kWinLdsFloats = 2 * kWinKc * (129 + 129 + 33);
+__global__ __launch_bounds__(256, 2) void lstm_window_dw_kernel(WinDwGroup grp, int K, int kslab) {
+  extern __shared__ float wlds[];
+  constexpr int H = 128, G = 512, KC = kWinKc;
+  const WinDwInst& g = grp.in[blockIdx.z];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int row0 = blockIdx.x * 128, o = g.o;
+  const int kbeg = blockIdx.y * kslab, kend = min(K, kbeg + kslab);
+  float* As = wlds;                          // [2][KC][129]
+  float* Bs = As + 2 * KC * 129;             // [2][KC][129]
+  float* Xs = Bs + 2 * KC * 129;             // [2][KC][33]
+  f32x16 acc[5];
+#pragma unroll
+  for (int c = 0; c < 5; ++c)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+  float rs = 0.f;
+  float av[16], bv[16], xv[4];
+  const int c128 = tid & 127, kk0 = tid >> 7;
+  auto request = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int k = k0 + kk0 + 2 * u;
+      const bool ok = k < kend;
+      av[u] = ok ? g.dgates[(long)k * G + row0 + c128] : 0.f;
+      bv[u] = ok ? g.hprev[(long)k * H + c128] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + 256 * u, kk = e >> 5, c = e & 31;
+      xv[u] = (c < o && k0 + kk < kend) ? g.x[(long)(k0 + kk) * o + c] : 0.f;
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      As[(buf * KC + kk0 + 2 * u) * 129 + c128] = av[u];
+      Bs[(buf * KC + kk0 + 2 * u) * 129 + c128] = bv[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + 256 * u;
+      Xs[(buf * KC + (e >> 5)) * 33 + (e & 31)] = xv[u];
+    }
+  };
+  if (kbeg < kend) {
+    request(kbeg);
+    commit(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += KC, buf ^= 1) {
+    const bool more = k0 + KC < kend;
+    if (more) request(k0 + KC);
+    const float* a_ = As + buf * KC * 129 + 32 * wave + r;
+    const float* b_ = Bs + buf * KC * 129 + r;
+    const float* x_ = Xs + buf * KC * 33 + r;
+#pragma unroll 4
+    for (int k = 0; k < KC; k += 2) {
+      const float a = a_[(k + h) * 129];
+      rs += a;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b_[(k + h) * 129 + 32 * c], acc[c], 0, 0, 0);
+      acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x_[(k + h) * 33], acc[4], 0, 0, 0);
+    }
+    if (more) commit(buf ^ 1);               // the other buffer: its readers finished before the previous barrier
+    __syncthreads();
+  }
+  // this slab's partial results: [G*H | G*o | G]
+  float* sl = g.slab + (long)blockIdx.y * (G * H + G * o + G);
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sl[(long)(row0 + 32 * wave + drow16(i, h)) * H + 32 * c + r] = acc[c][i];
+  if (r < o) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sl[(long)G * H + (long)(row0 + 32 * wave + drow16(i, h)) * o + r] = acc[4][i];
+  }
+  rs += __shfl_xor(rs, 32);
+  if (h == 0) sl[(long)G * H + (long)G * o + row0 + 32 * wave + r] = rs;
+}
+
+// Sum over the slabs in slab order, added to the gradient tensors (bias_ih and bias_hh share theirs).
+__global__ __launch_bounds__(256) void lstm_window_dw_reduce_kernel(WinDwGroup grp, int splits) {
+  __shared__ float part[8][33];
+  constexpr int H = 128, G = 512;
+  const WinDwInst& g = grp.in[blockIdx.y];
+  const int P = G * H + G * g.o + G;
+  const int c = threadIdx.x & 31, grp8 = threadIdx.x >> 5, e = blockIdx.x * 32 + c;
+  float s = 0.f;
+  if (e < P)
+    for (int sp = grp8; sp < splits; sp += 8) s += g.slab[(long)sp * P + e];
+  part[grp8][c] = s;
+  __syncthreads();
+  if (grp8 == 0 && e < P) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += part[k][c];
+    if (e < G * H) g.g_hh[e] += t;
+    else if (e < G * H + G * g.o) g.g_ih[e - G * H] += t;
+    else {
+      g.g_bih[e - G * H - G * g.o] += t;
+      g.g_bhh[e - G * H - G * g.o] += t;
+    }
+  }
+}
+
 long hhrl_lstm_workspace_floats(int B, int T, int o, int H) {
   if (B <= 0 || T <= 0 || o <= 0 || H <= 0) return 0;
   return carve(nullptr, B, T, o, H).total;
@@ -1108,15 +1239,47 @@ int hhrl_lstm_backward_group(const hhrl_lstm_desc* d, int n, int B, int T, int H
   }
   // weight gradients of the whole window: rows (t,b) of dgates against x_tm / previous hidden state
   {
+    bool win = n <= kMaxInst;
+    for (int i = 0; i < n; ++i) win = win && win_splits(B, T, d[i].o, H) > 0;
     GemmArgs dw[3 * kMaxInst];
     int m = 0;
+    if (win) {
+      // long reductions: the dedicated kernel for the forward direction's two products and the bias sums
+      WinDwGroup wg;
+      int splits = 32, omax = 0;
+      for (int i = 0; i < n; ++i) {
+        wg.in[i] = WinDwInst{w[i].dgates, w[i].hbuf, w[i].x_tm, w[i].dwslab, d[i].grads[0], d[i].grads[1], d[i].grads[2], d[i].grads[3], d[i].o};
+        const int sp = win_splits(B, T, d[i].o, H);
+        splits = sp < splits ? sp : splits;
+        omax = d[i].o > omax ? d[i].o : omax;
+      }
+      // about two workgroups per CU over the group (four row tiles per module and slab)
+      while (splits > 4 && 4L * n * splits > 640) --splits;
+      const int K = T * B;
+      const int kslab = ceil_div(ceil_div(K, splits), kWinKc) * kWinKc;
+      splits = ceil_div(K, kslab);
+      HHRL_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(lstm_window_dw_kernel), kWinLdsFloats * 4, "lstm_window_dw"));
+      {
+        ProfScope ps("lstm_window_dw_kernel", st, 2.0 * K * G * (H + (double)omax) * n, 4.0 * n * K * (double)(G + H + omax));
+        hipLaunchKernelGGL(lstm_window_dw_kernel, dim3(G / 128, splits, n), dim3(256), kWinLdsFloats * 4, st, wg, K, kslab);
+        HHRL_TRY(launch_status("lstm_window_dw_kernel"));
+      }
+      {
+        const int P = G * H + G * omax + G;
+        ProfScope ps("lstm_window_dw_reduce_kernel", st, 0.0, 4.0 * n * (double)P * (splits + 2));
+        hipLaunchKernelGGL(lstm_window_dw_reduce_kernel, dim3(ceil_div(P, 32), n), dim3(256), 0, st, wg, splits);
+        HHRL_TRY(launch_status("lstm_window_dw_reduce_kernel"));
+      }
+    }
     for (int i = 0; i < n; ++i) {
       const int o = d[i].o;
-      dw[m++] = gemm_args(w[i].dgates, 1, G, w[i].x_tm, o, 1, d[i].grads[0], o, G, o, T * B, nullptr, HHRL_ACT_NONE, 2);
-      dw[m] = gemm_args(w[i].dgates, 1, G, w[i].hbuf, H, 1, d[i].grads[1], H, G, H, T * B, nullptr, HHRL_ACT_NONE, 2);
-      // bias_ih and bias_hh share a gradient, the column sums of dgates: the row sums of this product's operand
-      dw[m].rowsum = d[i].grads[2];
-      dw[m++].rowsum2 = d[i].grads[3];
+      if (!win) {
+        dw[m++] = gemm_args(w[i].dgates, 1, G, w[i].x_tm, o, 1, d[i].grads[0], o, G, o, T * B, nullptr, HHRL_ACT_NONE, 2);
+        dw[m] = gemm_args(w[i].dgates, 1, G, w[i].hbuf, H, 1, d[i].grads[1], H, G, H, T * B, nullptr, HHRL_ACT_NONE, 2);
+        // bias_ih and bias_hh share a gradient, the column sums of dgates: the row sums of this product's operand
+        dw[m].rowsum = d[i].grads[2];
+        dw[m++].rowsum2 = d[i].grads[3];
+      }
       dw[m] = gemm_args(w[i].dgates_r, 1, G, w[i].x_tm + (long)(T - 1) * B * o, o, 1, d[i].grads[4], o, G, o, B, nullptr,
                         HHRL_ACT_NONE, 2);
       dw[m].rowsum = d[i].grads[6];

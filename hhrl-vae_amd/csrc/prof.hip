@@ -4,6 +4,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -21,6 +22,23 @@ static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_free;
 
 bool prof_on() { return g_prof; }
+
+// HHRL_PROF_SHAPES=1: launch sites that serve many shapes (the product kernels) report per shape
+bool prof_shapes() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("HHRL_PROF_SHAPES");
+    on = (e && atoi(e) == 1) ? 1 : 0;
+  }
+  return g_prof && on == 1;
+}
+
+// A name that stays valid for the life of the process (records keep the pointer)
+const char* prof_intern(const char* name) {
+  static std::set<std::string> names;
+  std::lock_guard<std::mutex> lk(g_mu);
+  return names.insert(name).first->c_str();
+}
 
 static hipEvent_t get_event() {
   if (!g_free.empty()) {

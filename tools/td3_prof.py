@@ -21,8 +21,9 @@ lib.hhrl_prof_enable(0)
 rep = _lib.prof_report()
 tot = sum(v['ms'] for v in rep.values()); nl = sum(v['launches'] for v in rep.values())
 print(which, 'wall ms/update (profiling on)', 1e3*dt/K, 'gpu-kernel ms/update', tot/K, 'launches/update', nl/K)
-for k, v in sorted(rep.items(), key=lambda kv: -kv[1]['ms']): print('  %-32s %6.1f launches %8.3f ms/update  %6.1f us avg' % (k, v['launches']/K, v['ms']/K, 1e3*v['ms']/v['launches']))
+for k, v in sorted(rep.items(), key=lambda kv: -kv[1]['ms']): print('  %-32s %6.1f launches %8.3f ms/update  %6.1f us avg  %6.1f TFLOP/s' % (k, v['launches']/K, v['ms']/K, 1e3*v['ms']/v['launches'], v['flops']/(v['ms']*1e-3)/1e12 if v['ms'] > 0 else 0.0))
 lib.hhrl_prof_reset()
+if os.environ.get('TD3_PROF_ONLY') == '1': sys.exit(0)
 for ug in (False, True, "auto"):
     net = mk(ug)
     net.memory[:n] = np.random.RandomState(1).uniform(0, 1, size=(n, net.fam.row_width)); net.pointer = n
