@@ -224,6 +224,10 @@ def agent_update_rates(device, steps: int, group=None, world: int = 1, cpu_basel
                      "roofline": dict(work.roofline(w["flops"], w["bytes"], dt / n_timed),
                                       flops_per_update=w["flops"], bytes_per_update=w["bytes"], macs_per_row=w["macs_per_row"]),
                      "launch_forms": sorted(set(net.launch_forms().values()))}
+        prof_cfg = "%s_b%d" % (kind, batch)
+        summary = td3_profile_summary(prof_cfg)
+        if summary is not None:
+            out[name]["roofline"].update(summary)
         if group is None and extras:
             # one policy evaluation as the agents call it every control step (host round trip included)
             fam = net.fam
@@ -329,6 +333,49 @@ def pmc_traffic(workload: str, kernel: str, suffix: str = "_hbm_traffic.json", f
         if d.get("workload") == workload and k is not None:
             best = {"bytes": k[field], "source": os.path.relpath(path, ROOT)}
     return best
+
+
+def td3_profile_summary(cfg: str):
+    """What the newest committed rocprofv3 summaries of an agent-update configuration (tools/profile_td3.sh ->
+    profiles/<tag>_td3_<cfg>_*) say: the kernel with the largest share of the update, its matrix-pipe busy share,
+    the HBM bytes one update moves and the matrix FLOPs it executes.  None when no summary covers the configuration."""
+    import csv
+    import glob
+    import re
+
+    def order(path):
+        return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(path))]
+
+    def newest(suffix):
+        hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_td3_%s_%s" % (cfg, suffix))), key=order)
+        return hits[-1] if hits else None
+    out = {}
+    stats = newest("kernel_stats.csv")
+    if stats is not None:
+        rows = []
+        with open(stats, newline="") as f:
+            for row in csv.reader(l for l in f if not l.startswith("#")):
+                if row and row[0] != "Name" and "hhrl::" in row[0]:
+                    rows.append((int(row[2]), row[0], float(row[3]) / 1e3, float(row[4])))
+        if rows:
+            tot, name, avg_us, pct = max(rows)
+            short = name.split("(")[0].replace("void ", "").split("::")[-1]
+            out.update(kernel=short, kernel_avg_launch_us=avg_us, kernel_share_of_gpu_time=pct / 100.0,
+                       kernel_stats_source=os.path.relpath(stats, ROOT))
+    for suffix, pick in (("mfma_util.json", lambda d: {"executed_matrix_flops_per_update": d.get("executed_matrix_flops_per_update"),
+                                                       "mfma_busy": (d["kernels"].get(out.get("kernel"), {}) or {}).get("mfma_busy_frac")}),
+                         ("hbm_traffic.json", lambda d: {"traffic": d.get("hbm_bytes_per_update"), "traffic_unit": "bytes per update"})):
+        path = newest(suffix)
+        if path is None:
+            continue
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            out.update(pick(d))
+            out[suffix.split(".")[0] + "_source"] = os.path.relpath(path, ROOT)
+        except (OSError, ValueError, KeyError):
+            pass
+    return out or None
 
 
 def _free_port() -> int:

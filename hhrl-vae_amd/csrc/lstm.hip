@@ -35,7 +35,12 @@ static int win_splits(long B, long T, long o, long H) {
   const long K = T * B;
   if (H != 128 || o > 32 || K < kWinMinRows) return 0;
   const long s = (K + 4 * kWinKc - 1) / (4 * kWinKc);      // at least four chunks per slab
-  return (int)(s < 32 ? s : 32);
+  return (int)(s < 64 ? s : 64);
+}
+// slabs of the reverse direction's B rows in the same launch
+static int win_splits_rev(long B) {
+  const long s = (B + 4 * kWinKc - 1) / (4 * kWinKc);
+  return (int)(s < 8 ? s : 8);
 }
 
 static LstmWs carve(float* ws, long B, long T, long o, long H) {
@@ -54,7 +59,7 @@ static LstmWs carve(float* ws, long B, long T, long o, long H) {
   w.dcat = take(B * 2 * H);
   w.dc = take(B * H);
   w.dh = take(B * H);
-  w.dwslab = take((long)win_splits(B, T, o, H) * (4 * H * H + 4 * H * o + 4 * H));
+  w.dwslab = take(win_splits(B, T, o, H) > 0 ? (long)(win_splits(B, T, o, H) + win_splits_rev(B)) * (4 * H * H + 4 * H * o + 4 * H) : 0);
   w.total = off;
   return w;
 }
@@ -896,16 +901,26 @@ extern "C" {
 // chunk's loads in flight during the products) and every staged dgates element feeds 160 products: 33 FLOP per byte
 // fetched, against 8 for 32 x 32 output tiles.  The slabs' partial results go to the workspace and are summed in slab
 // order by lstm_window_dw_reduce_kernel (the same bits on every run; no atomics).
-struct WinDwInst { const float *dgates, *hprev, *x; float *slab, *g_ih, *g_hh, *g_bih, *g_bhh; int o; };
+struct WinDwInst {
+  const float *dgates, *hprev, *x;            // forward direction: rows (t, b) of the window
+  const float *dgates_r, *x_r;                // reverse direction: its single step on the last observation (hprev = 0)
+  float *slab, *g_ih, *g_hh, *g_bih, *g_bhh, *g_ih_r, *g_bih_r, *g_bhh_r;
+  int o;
+};
 struct WinDwGroup { WinDwInst in[kMaxInst]; };
 constexpr int kWinLdsFloats = 2 * kWinKc * (129 + 129 + 33);
-__global__ __launch_bounds__(256, 2) void lstm_window_dw_kernel(WinDwGroup grp, int K, int kslab) {
+__global__ __launch_bounds__(256, 2) void lstm_window_dw_kernel(WinDwGroup grp, int K, int kslab, int splits, int Kr, int kslab_r) {
   extern __shared__ float wlds[];
   constexpr int H = 128, G = 512, KC = kWinKc;
   const WinDwInst& g = grp.in[blockIdx.z];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int row0 = blockIdx.x * 128, o = g.o;
-  const int kbeg = blockIdx.y * kslab, kend = min(K, kbeg + kslab);
+  // slabs [0, splits): the forward direction's rows; the rest: the reverse direction's B rows (no recurrent part)
+  const bool rev = (int)blockIdx.y >= splits;
+  const int kbeg = rev ? ((int)blockIdx.y - splits) * kslab_r : blockIdx.y * kslab;
+  const int kend = rev ? min(Kr, kbeg + kslab_r) : min(K, kbeg + kslab);
+  const float* dg = rev ? g.dgates_r : g.dgates;
+  const float* xin = rev ? g.x_r : g.x;
   float* As = wlds;                          // [2][KC][129]
   float* Bs = As + 2 * KC * 129;             // [2][KC][129]
   float* Xs = Bs + 2 * KC * 129;             // [2][KC][33]
@@ -922,13 +937,13 @@ __global__ __launch_bounds__(256, 2) void lstm_window_dw_kernel(WinDwGroup grp, 
     for (int u = 0; u < 16; ++u) {
       const int k = k0 + kk0 + 2 * u;
       const bool ok = k < kend;
-      av[u] = ok ? g.dgates[(long)k * G + row0 + c128] : 0.f;
-      bv[u] = ok ? g.hprev[(long)k * H + c128] : 0.f;
+      av[u] = ok ? dg[(long)k * G + row0 + c128] : 0.f;
+      bv[u] = (ok && !rev) ? g.hprev[(long)k * H + c128] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int e = tid + 256 * u, kk = e >> 5, c = e & 31;
-      xv[u] = (c < o && k0 + kk < kend) ? g.x[(long)(k0 + kk) * o + c] : 0.f;
+      xv[u] = (c < o && k0 + kk < kend) ? xin[(long)(k0 + kk) * o + c] : 0.f;
     }
   };
   auto commit = [&](int buf) {
@@ -959,8 +974,10 @@ __global__ __launch_bounds__(256, 2) void lstm_window_dw_kernel(WinDwGroup grp, 
     for (int k = 0; k < KC; k += 2) {
       const float a = a_[(k + h) * 129];
       rs += a;
+      if (!rev) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b_[(k + h) * 129 + 32 * c], acc[c], 0, 0, 0);
+        for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b_[(k + h) * 129 + 32 * c], acc[c], 0, 0, 0);
+      }
       acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x_[(k + h) * 33], acc[4], 0, 0, 0);
     }
     if (more) commit(buf ^ 1);               // the other buffer: its readers finished before the previous barrier
@@ -968,10 +985,12 @@ __global__ __launch_bounds__(256, 2) void lstm_window_dw_kernel(WinDwGroup grp, 
   }
   // this slab's partial results: [G*H | G*o | G]
   float* sl = g.slab + (long)blockIdx.y * (G * H + G * o + G);
+  if (!rev) {
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) sl[(long)(row0 + 32 * wave + drow16(i, h)) * H + 32 * c + r] = acc[c][i];
+      for (int i = 0; i < 16; ++i) sl[(long)(row0 + 32 * wave + drow16(i, h)) * H + 32 * c + r] = acc[c][i];
+  }
   if (r < o) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) sl[(long)G * H + (long)(row0 + 32 * wave + drow16(i, h)) * o + r] = acc[4][i];
@@ -980,27 +999,40 @@ __global__ __launch_bounds__(256, 2) void lstm_window_dw_kernel(WinDwGroup grp, 
   if (h == 0) sl[(long)G * H + (long)G * o + row0 + 32 * wave + r] = rs;
 }
 
-// Sum over the slabs in slab order, added to the gradient tensors (bias_ih and bias_hh share theirs).
-__global__ __launch_bounds__(256) void lstm_window_dw_reduce_kernel(WinDwGroup grp, int splits) {
-  __shared__ float part[8][33];
+// Sum over the slabs in slab order, added to the gradient tensors (bias_ih and bias_hh share theirs); the
+// reverse direction's slabs follow the forward ones and have no recurrent part.
+__global__ __launch_bounds__(256) void lstm_window_dw_reduce_kernel(WinDwGroup grp, int splits, int splits_r) {
+  __shared__ float part[2][8][33];
   constexpr int H = 128, G = 512;
   const WinDwInst& g = grp.in[blockIdx.y];
   const int P = G * H + G * g.o + G;
   const int c = threadIdx.x & 31, grp8 = threadIdx.x >> 5, e = blockIdx.x * 32 + c;
-  float s = 0.f;
-  if (e < P)
+  float s = 0.f, sr = 0.f;
+  if (e < P) {
     for (int sp = grp8; sp < splits; sp += 8) s += g.slab[(long)sp * P + e];
-  part[grp8][c] = s;
+    if (e >= G * H)
+      for (int sp = splits + grp8; sp < splits + splits_r; sp += 8) sr += g.slab[(long)sp * P + e];
+  }
+  part[0][grp8][c] = s;
+  part[1][grp8][c] = sr;
   __syncthreads();
   if (grp8 == 0 && e < P) {
-    float t = 0.f;
+    float t = 0.f, tr = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += part[k][c];
+    for (int k = 0; k < 8; ++k) {
+      t += part[0][k][c];
+      tr += part[1][k][c];
+    }
     if (e < G * H) g.g_hh[e] += t;
-    else if (e < G * H + G * g.o) g.g_ih[e - G * H] += t;
-    else {
-      g.g_bih[e - G * H - G * g.o] += t;
-      g.g_bhh[e - G * H - G * g.o] += t;
+    else if (e < G * H + G * g.o) {
+      g.g_ih[e - G * H] += t;
+      g.g_ih_r[e - G * H] += tr;
+    } else {
+      const int b = e - G * H - G * g.o;
+      g.g_bih[b] += t;
+      g.g_bhh[b] += t;
+      g.g_bih_r[b] += tr;
+      g.g_bhh_r[b] += tr;
     }
   }
 }
@@ -1034,7 +1066,15 @@ int hhrl_lstm_forward_group(const hhrl_lstm_desc* d, int n, int B, int T, int H,
                             w[i].cat, w[i].gates_r, w[i].c_r, d[i].ldobs, d[i].o};
     }
     const int chunks = ceil_div(B, 4);
-    const int gx_f = seq_grid_x(chunks, n), gx_r = gx_f >= 4 ? gx_f / 4 : 1;
+    // One round of the 256 CUs for the forward and the reverse workgroups of all modules (243 in all: a workgroup that
+    // has to wait for a CU starts when a forward workgroup ends and doubles the launch).  A reverse workgroup runs
+    // ONE step per group of four rows against T for a forward one, so a ninth of a module's workgroups keeps pace
+    // (nine modules at batch 1024: 24 + 3 per module instead of 22 + 5, 225 -> 200 us).
+    const int per = 243 / n > 2 ? 243 / n : 2;
+    int gx_r = per / 9 > 1 ? per / 9 : 1;
+    int gx_f = per - gx_r;
+    if (gx_f > chunks) gx_f = chunks;
+    if (gx_r > chunks) gx_r = chunks;
     const dim3 grid(gx_r + gx_f, 1, n);
     const size_t lds_fwd = 4 * (size_t)(SQ_SLAB + T * 4 * 32);
     HHRL_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(lstm_seq_forward_kernel<16>), (int)lds_fwd, "lstm"));
@@ -1246,28 +1286,35 @@ int hhrl_lstm_backward_group(const hhrl_lstm_desc* d, int n, int B, int T, int H
     if (win) {
       // long reductions: the dedicated kernel for the forward direction's two products and the bias sums
       WinDwGroup wg;
-      int splits = 32, omax = 0;
+      int splits = 64, omax = 0;
       for (int i = 0; i < n; ++i) {
-        wg.in[i] = WinDwInst{w[i].dgates, w[i].hbuf, w[i].x_tm, w[i].dwslab, d[i].grads[0], d[i].grads[1], d[i].grads[2], d[i].grads[3], d[i].o};
-        const int sp = win_splits(B, T, d[i].o, H);
+        const int o = d[i].o;
+        wg.in[i] = WinDwInst{w[i].dgates, w[i].hbuf, w[i].x_tm, w[i].dgates_r, w[i].x_tm + (long)(T - 1) * B * o, w[i].dwslab,
+                             d[i].grads[0], d[i].grads[1], d[i].grads[2], d[i].grads[3], d[i].grads[4], d[i].grads[6], d[i].grads[7], o};
+        const int sp = win_splits(B, T, o, H);
         splits = sp < splits ? sp : splits;
-        omax = d[i].o > omax ? d[i].o : omax;
+        omax = o > omax ? o : omax;
       }
       // about two workgroups per CU over the group (four row tiles per module and slab)
       while (splits > 4 && 4L * n * splits > 640) --splits;
       const int K = T * B;
       const int kslab = ceil_div(ceil_div(K, splits), kWinKc) * kWinKc;
       splits = ceil_div(K, kslab);
+      int splits_r = win_splits_rev(B);
+      const int kslab_r = ceil_div(ceil_div(B, splits_r), kWinKc) * kWinKc;
+      splits_r = ceil_div(B, kslab_r);
       HHRL_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(lstm_window_dw_kernel), kWinLdsFloats * 4, "lstm_window_dw"));
       {
-        ProfScope ps("lstm_window_dw_kernel", st, 2.0 * K * G * (H + (double)omax) * n, 4.0 * n * K * (double)(G + H + omax));
-        hipLaunchKernelGGL(lstm_window_dw_kernel, dim3(G / 128, splits, n), dim3(256), kWinLdsFloats * 4, st, wg, K, kslab);
+        ProfScope ps("lstm_window_dw_kernel", st, 2.0 * G * ((double)K * (H + omax) + (double)B * omax) * n,
+                     4.0 * n * (K + (double)B) * (G + H + omax));
+        hipLaunchKernelGGL(lstm_window_dw_kernel, dim3(G / 128, splits + splits_r, n), dim3(256), kWinLdsFloats * 4, st, wg, K, kslab,
+                           splits, B, kslab_r);
         HHRL_TRY(launch_status("lstm_window_dw_kernel"));
       }
       {
         const int P = G * H + G * omax + G;
-        ProfScope ps("lstm_window_dw_reduce_kernel", st, 0.0, 4.0 * n * (double)P * (splits + 2));
-        hipLaunchKernelGGL(lstm_window_dw_reduce_kernel, dim3(ceil_div(P, 32), n), dim3(256), 0, st, wg, splits);
+        ProfScope ps("lstm_window_dw_reduce_kernel", st, 0.0, 4.0 * n * (double)P * (splits + splits_r + 2));
+        hipLaunchKernelGGL(lstm_window_dw_reduce_kernel, dim3(ceil_div(P, 32), n), dim3(256), 0, st, wg, splits, splits_r);
         HHRL_TRY(launch_status("lstm_window_dw_reduce_kernel"));
       }
     }
@@ -1279,11 +1326,11 @@ int hhrl_lstm_backward_group(const hhrl_lstm_desc* d, int n, int B, int T, int H
         // bias_ih and bias_hh share a gradient, the column sums of dgates: the row sums of this product's operand
         dw[m].rowsum = d[i].grads[2];
         dw[m++].rowsum2 = d[i].grads[3];
+        dw[m] = gemm_args(w[i].dgates_r, 1, G, w[i].x_tm + (long)(T - 1) * B * o, o, 1, d[i].grads[4], o, G, o, B, nullptr,
+                          HHRL_ACT_NONE, 2);
+        dw[m].rowsum = d[i].grads[6];
+        dw[m++].rowsum2 = d[i].grads[7];
       }
-      dw[m] = gemm_args(w[i].dgates_r, 1, G, w[i].x_tm + (long)(T - 1) * B * o, o, 1, d[i].grads[4], o, G, o, B, nullptr,
-                        HHRL_ACT_NONE, 2);
-      dw[m].rowsum = d[i].grads[6];
-      dw[m++].rowsum2 = d[i].grads[7];
     }
     // (each of these has at most 16 x 4 output tiles: always the small-product kernels, which honour rowsum)
     for (int base = 0; base < m; base += kGemmGroupMax)

@@ -64,7 +64,7 @@ def td3_inputs(case: str, fx: Dict[str, np.ndarray], shapes_by_net):
     return init, rows
 
 
-def adam_path_close(name, got_p, want_p, grads_by_step, lrs, g_floor=2e-6, rtol=1e-4):
+def adam_path_close(name, got_p, want_p, grads_by_step, lrs, g_floor=2e-6, rtol=1e-4, max_saturated=None):
     """Parameters after a sequence of Adam steps, element by element.
 
     Adam normalises the gradient: a step moves a weight by about lr * g/|g| while the moments are young, so a
@@ -74,16 +74,33 @@ def adam_path_close(name, got_p, want_p, grads_by_step, lrs, g_floor=2e-6, rtol=
     the rtol of the specification plus a scale floor plus the SUM of those per-step terms: it stays tight for
     every element whose gradient is well above the noise and does not grow with the number of steps for them.
 
-    grads_by_step: list of {tensor name: reference gradient at that step}; lrs: the lr of each step."""
+    grads_by_step: list of {tensor name: reference gradient at that step}; lrs: the lr of each step.
+
+    An element whose gradient sits in the noise at most steps ends up with an allowance near 2.2 * sum(lr), the
+    furthest Adam can move a weight at all: it is then effectively unchecked.  The share of such elements
+    (allowance beyond half of that ceiling) over all tensors is returned, and with max_saturated it is asserted
+    to stay below that share, so that the check cannot quietly turn into one that passes anything."""
     acc = {k: 0.0 for k in want_p}
     for grads, lr in zip(grads_by_step, lrs):
         for k in want_p:
             g = np.abs(np.asarray(grads[k], dtype=np.float64))
             dg = g_floor * max(float(g.max()) if g.size else 0.0, 1e-30)
             acc[k] = acc[k] + lr * np.minimum(2.2, 6.0 * dg / (g + 1e-30))
+    ceiling = 2.2 * float(sum(lrs))
+    n_sat = n_all = 0
     for k, w in want_p.items():
         wp, gp = np.asarray(w, dtype=np.float64), np.asarray(got_p[k], dtype=np.float64)
         tol = rtol * np.abs(wp) + 2e-6 * float(np.abs(wp).max() if wp.size else 0.0) + acc[k]
         err = np.abs(gp - wp)
         assert np.all(err <= tol), "%s/%s: %d of %d elements out, worst excess %.3e (bar there %.3e)" % (
             name, k, int((err > tol).sum()), err.size, float((err - tol).max()), float(tol.reshape(-1)[np.argmax(err - tol)]))
+        if ceiling > 0:
+            n_sat += int(np.sum(np.broadcast_to(acc[k], wp.shape) > 0.5 * ceiling))
+        n_all += wp.size
+    frac = n_sat / max(n_all, 1)
+    print("adam_path_close %s: %d of %d elements (%.2f %%) carry an allowance beyond half of Adam's reach over %d steps"
+          % (name, n_sat, n_all, 100.0 * frac, len(lrs)))
+    if max_saturated is not None:
+        assert frac <= max_saturated, "%s: %.1f %% of the elements are effectively unchecked (allowed: %.1f %%)" % (
+            name, 100.0 * frac, 100.0 * max_saturated)
+    return frac

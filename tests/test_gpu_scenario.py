@@ -125,21 +125,27 @@ def test_four_intersections_stream_matches_oracle():
     # allow.  G_FLOOR is the relative uncertainty of a gradient between the two runs: their minibatches hold
     # actions and advised speeds that the runs computed themselves and that agree to 2e-4 of scale (above), and
     # a gradient inherits the relative spread of its inputs.  A target follows its network (tau = 0.005 per
-    # policy step), so the network's bar bounds it too.
+    # policy step), so the network's bar bounds it too.  What that bar still checks: an element whose gradient sits
+    # below ~3 G_FLOOR of its tensor's largest at most steps is allowed nearly all of Adam's reach and is in effect
+    # unchecked at the end (it is checked through everything it feeds: the actions and replay rows above, the losses
+    # and gradients of the kernel tests).  adam_path_close reports that share per network (measured: 31-42 % of the
+    # manager's elements over 14 / 7 steps, 44-59 % of the worker's over 224 / 112); MAX_SATURATED keeps it from
+    # growing unnoticed, e.g. through a larger G_FLOOR.
     G_FLOOR = 2e-4
+    MAX_SATURATED = 0.65
     for net, onet, tag in ((mgr, o_mgr, "manager"), (wrk, o_wrk, "worker")):
         steps = onet.td3.total_it
         assert net.total_it == steps > 0 and len(onet.grad_log["critic"]) == steps
         sds, tgt = net.state_dicts(), net.target_state_dicts()
         np_ = lambda d: {k: v.detach().cpu().numpy() for k, v in d.items()}
         adam_path_close(tag + "/critic", np_(sds["critic"]), np_(onet.td3.critic), onet.grad_log["critic"],
-                        onet.lr_log["critic"], g_floor=G_FLOOR)
+                        onet.lr_log["critic"], g_floor=G_FLOOR, max_saturated=MAX_SATURATED)
         adam_path_close(tag + "/critic_target", np_(tgt["critic"]), np_(onet.td3.critic_target), onet.grad_log["critic"],
                         onet.lr_log["critic"], g_floor=G_FLOOR)
         for k, nme in enumerate(net.actor_names):
             assert len(onet.grad_log[nme]) == steps // 2
             adam_path_close(tag + "/" + nme, np_(sds[nme]), np_(onet.td3.actors[k]), onet.grad_log[nme], onet.lr_log[nme],
-                            g_floor=G_FLOOR)
+                            g_floor=G_FLOOR, max_saturated=MAX_SATURATED)
             adam_path_close(tag + "/" + nme + "_target", np_(tgt[nme]), np_(onet.td3.actor_targets[k]), onet.grad_log[nme],
                             onet.lr_log[nme], g_floor=G_FLOOR)
 

@@ -248,14 +248,26 @@ def test_vae_fused_matches_layerwise(B, N, g):
     eps = torch.randn(B, g, generator=torch.Generator().manual_seed(B * N)).cuda()
     lf, ll = float(ef.loss_and_grads(x, eps)), float(el.loss_and_grads(x, eps))
     assert_close("loss", lf, ll, rtol=1e-4, atol=0)
-    # two fp32 evaluations in different summation orders: elements above 5e-4 of their tensor's largest
-    # entry (1e-5 for small batches) must agree to rtol 1e-4; accuracy itself is judged against the
-    # oracle and its fp64 yardstick in test_vae_full_size_vs_oracle.  The allowance is not all rounding of
-    # sums: among the 3.7 M hidden pre-activations of 4096 x 7 cars one or two lie within rounding of zero,
-    # and the two paths' forward products may put such a value on different sides of the ReLU, which switches
-    # that car's whole contribution through that unit (measured: one row of func.0's input gradient, 2.4e-4 of
-    # the largest entry of decoder.0's weight gradient).
-    dict_close("grad", _np(ef.grads()), _np(el.grads()), atol_rel=1e-5 if B * N < 4096 else 5e-4)
+    # Two fp32 evaluations in different summation orders (accuracy itself is judged against the oracle and its fp64
+    # yardstick in test_vae_full_size_vs_oracle).  Small batches: 1e-5 of a tensor's largest entry.  From 4096 cars
+    # on: 3e-5 for the longer sums, and an allowance for ReLU flips: among millions of hidden pre-activations one or
+    # two lie within rounding of zero, the two paths may put such a value on different sides of the ReLU, and that
+    # switches ONE car's whole contribution through that unit -- a change of the order of 1/(B*N) of a sum over all
+    # cars, spread over the gradient tensors upstream of the unit (tests/diag_vae_fused_vs_layerwise.py: 2.4e-4 of
+    # decoder.0's largest weight gradient at 4096 x 7 = 28672 cars, nothing beyond 1e-5 at 20000 x 7 or 2048 x 59).
+    # The allowance is therefore 8/(B*N) per element, and at most 5 % of all elements may use it.
+    gf, gl = _np(ef.grads()), _np(el.grads())
+    if B * N < 4096:
+        dict_close("grad", gf, gl, atol_rel=1e-5)
+    else:
+        base, flip = 3e-5, 8.0 / (B * N)
+        dict_close("grad", gf, gl, atol_rel=base + flip)
+        beyond = total = 0
+        for k in gl:
+            a, b = gf[k].astype(np.float64), gl[k].astype(np.float64)
+            beyond += int((np.abs(a - b) > 1e-4 * np.abs(b) + base * np.abs(b).max()).sum())
+            total += b.size
+        assert beyond <= 0.05 * total, "%d of %d gradient elements beyond the summation-order bar" % (beyond, total)
     # same inputs, same bits: every sum of the fused step runs in a fixed order
     g1 = _np(ef.grads())
     ef.loss_and_grads(x, eps)

@@ -13,7 +13,9 @@ kept under profiles/:
 
 usage: python tools/summarize_prof.py <tag>        (on the CPU box, after the GPU call has merged its files)
        python tools/summarize_prof.py --td3 <tag>  (tools/profile_td3.sh <tag>: <tag>_td3_<config>_kernel_stats.csv,
-                                                    each with the traced run's wall time per update in a comment line)
+                                                    each with the traced run's wall time per update in a comment line;
+                                                    <tag>_td3_<config>_hbm_traffic.json and _mfma_util.json from the
+                                                    counter passes, per kernel of the update and per update)
 """
 import csv
 import glob
@@ -47,19 +49,107 @@ def counter_per_launch(path, counter):
     return {k: tot[k] / cnt[k] for k in tot}
 
 
+def short_name(full):
+    """hhrl::mf::mlp3_forward_kernel<false>(...) -> mlp3_forward_kernel<false>"""
+    n = full.split("(")[0].strip()
+    if n.startswith("void "):
+        n = n[5:]
+    head, _, tail = n.partition("<")
+    return head.split("::")[-1] + (("<" + tail) if tail else "")
+
+
+def counters_by_kernel(path, names):
+    """{kernel short name: {counter: (sum, dispatches)}} of one counter-collection CSV (our kernels only)."""
+    out = {}
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            if "hhrl::" not in row["Kernel_Name"] or row["Counter_Name"] not in names:
+                continue
+            d = out.setdefault(short_name(row["Kernel_Name"]), {})
+            t, c = d.get(row["Counter_Name"], (0.0, 0))
+            d[row["Counter_Name"]] = (t + float(row["Counter_Value"]), c + 1)
+    return out
+
+
+def td3_counters(d, cfg, tag, dst, avg_us, calls, updates):
+    """The counter passes of one configuration -> <tag>_td3_<cfg>_hbm_traffic.json / _mfma_util.json."""
+    fetch = glob.glob(d + "/fetch/**/*_counter_collection.csv", recursive=True)
+    write = glob.glob(d + "/write/**/*_counter_collection.csv", recursive=True)
+    mfma = glob.glob(d + "/mfma/**/*_counter_collection.csv", recursive=True)
+    workload = "td3_" + cfg
+    if len(fetch) == 1 and len(write) == 1:
+        fe, wr = counters_by_kernel(fetch[0], ("FETCH_SIZE",)), counters_by_kernel(write[0], ("WRITE_SIZE",))
+        doc = {"workload": workload,
+               "command": "tools/profile_td3.sh %s (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, one run each, 40 updates after warm-up)" % tag,
+               "correction": "read bytes = 2 x FETCH_SIZE (gfx950 tallies 128-B requests at 64 B); write bytes = WRITE_SIZE; "
+                             "counters are reported in KiB", "kernels": {}}
+        per_update = 0.0
+        for k in sorted(fe):
+            if k not in wr:
+                continue
+            f_avg = fe[k]["FETCH_SIZE"][0] / fe[k]["FETCH_SIZE"][1]
+            w_avg = wr[k]["WRITE_SIZE"][0] / wr[k]["WRITE_SIZE"][1]
+            b = 1024.0 * (2.0 * f_avg + w_avg)
+            lpu = calls.get(k, 0) / max(updates, 1)
+            doc["kernels"][k] = {"FETCH_SIZE_raw_KiB_per_launch": f_avg, "WRITE_SIZE_raw_KiB_per_launch": w_avg,
+                                 "hbm_bytes_per_launch": b, "launches_per_update": lpu,
+                                 "achieved_GBps": b / (avg_us[k] * 1e-6) / 1e9 if k in avg_us else None}
+            per_update += b * lpu
+        doc["hbm_bytes_per_update"] = per_update
+        with open(os.path.join(dst, "%s_td3_%s_hbm_traffic.json" % (tag, cfg)), "w") as f:
+            json.dump(doc, f, indent=1)
+            f.write("\n")
+        print("  %s: %.2f MB of HBM traffic per update" % (cfg, per_update / 1e6))
+    if len(mfma) == 1:
+        names = ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_BUSY_CYCLES", "SQ_WAVES", "GRBM_GUI_ACTIVE")
+        c = counters_by_kernel(mfma[0], names)
+        doc = {"workload": workload,
+               "command": "tools/profile_td3.sh %s (rocprofv3 --pmc %s, 40 updates after warm-up)" % (tag, " ".join(names)),
+               "definitions": "per launch; mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x the kernel-trace pass's average "
+                              "duration x 2.4 GHz); executed_matrix_flops = 512 x SQ_INSTS_VALU_MFMA_MOPS_F32; update totals weight "
+                              "every kernel by its launches per update in the kernel-trace pass", "kernels": {}}
+        busy_cyc = flops = 0.0
+        for k in sorted(c):
+            if "SQ_VALU_MFMA_BUSY_CYCLES" not in c[k] or k not in avg_us:
+                continue
+            avg = lambda n: c[k][n][0] / c[k][n][1] if n in c[k] else None
+            busy, mops = avg("SQ_VALU_MFMA_BUSY_CYCLES"), avg("SQ_INSTS_VALU_MFMA_MOPS_F32") or 0.0
+            cyc = avg_us[k] * 1e-6 * CLOCK_GHZ * 1e9
+            lpu = calls.get(k, 0) / max(updates, 1)
+            doc["kernels"][k] = {"avg_launch_us": avg_us[k], "launches_per_update": lpu, "SQ_VALU_MFMA_BUSY_CYCLES": busy,
+                                 "SQ_INSTS_VALU_MFMA_MOPS_F32": mops, "SQ_BUSY_CYCLES": avg("SQ_BUSY_CYCLES"), "SQ_WAVES": avg("SQ_WAVES"),
+                                 "GRBM_GUI_ACTIVE": avg("GRBM_GUI_ACTIVE"), "mfma_busy_frac": busy / (N_SIMD * cyc),
+                                 "executed_matrix_flops": 512.0 * mops, "executed_tflops": 512.0 * mops / (avg_us[k] * 1e-6) / 1e12}
+            busy_cyc += busy * lpu
+            flops += 512.0 * mops * lpu
+        doc["executed_matrix_flops_per_update"] = flops
+        doc["mfma_busy_simd_cycles_per_update"] = busy_cyc
+        with open(os.path.join(dst, "%s_td3_%s_mfma_util.json" % (tag, cfg)), "w") as f:
+            json.dump(doc, f, indent=1)
+            f.write("\n")
+        print("  %s: %.3f GFLOP executed on the matrix cores per update" % (cfg, flops / 1e9))
+
+
 def td3(tag):
     dst = os.path.join(ROOT, "profiles")
     for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "prof_%s_td3_*" % tag))):
         cfg = os.path.basename(d)[len("prof_%s_td3_" % tag):]
         line = open(os.path.join(d, "line.json")).read().strip().splitlines()[-1]
         out_path = os.path.join(dst, "%s_td3_%s_kernel_stats.csv" % (tag, cfg))
+        avg_us, calls = {}, {}
         with open(one(d + "/trace/**/*_kernel_stats.csv"), newline="") as f, open(out_path, "w", newline="") as out:
-            out.write("# rocprofv3 --kernel-trace --stats -- python3 tools/td3_trace.py %s 200 ; %s\n" % (cfg.replace("_b", " "), line))
+            out.write("# rocprofv3 --kernel-trace --stats -- python3 tools/td3_trace.py %s ; %s\n" % (cfg.replace("_b", " "), line))
             w = csv.writer(out)
-            for row in csv.reader(f):
+            rows = list(csv.reader(f))
+            for row in rows:
+                if row and row[0] != "Name" and "hhrl::" in row[0]:
+                    avg_us[short_name(row[0])] = float(row[3]) / 1e3
+                    calls[short_name(row[0])] = int(row[1])
                 row[0] = row[0][:160]
                 w.writerow(row)
         print(out_path, line)
+        info = json.loads(line)
+        td3_counters(d, cfg, tag, dst, avg_us, calls, info["updates"] + info.get("warmup_updates", 0))
 
 
 def main():
