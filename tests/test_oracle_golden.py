@@ -8,7 +8,16 @@ import gen
 import hhrl_oracle as O
 from golden_util import assert_close, assert_dict_close, load_case, sub, td3_inputs
 
-TOL = dict(rtol=2e-5, atol=1e-7)        # same ATen kernels on both sides: far tighter than the product bar
+# Same ATen operators on both sides, but not necessarily the same CPU: the BLAS picks its blocking (the order of
+# the fp32 sums) by micro-architecture, so the fixtures recorded on one host are met to summation noise on another.
+# Still far tighter than the product bar (rtol 1e-4 + 1e-5 of the tensor's largest entry).
+TOL = dict(rtol=2e-5, atol=1e-7, max_frac=5e-6)
+
+
+def PTOL(lr, steps):
+    """Parameters after `steps` Adam steps: a step moves a weight by about lr * g/|g|, which turns the summation
+    noise of a near-zero gradient element into a difference of a small share of lr."""
+    return dict(rtol=2e-5, atol=1e-7 + 1e-3 * lr * steps, max_frac=5e-6)
 
 
 def _t(d):
@@ -25,8 +34,8 @@ def test_vae_steps(g):
         assert_close("loss%d" % step, loss, fx["step%d/loss" % step], **TOL)
         if step == 0 and g == 4:
             assert_dict_close("grad0", {k: v.numpy() for k, v in vae.grads.items()}, sub(fx, "step0/grad"), **TOL)
-            assert_dict_close("param0", {k: v.detach().numpy() for k, v in vae.p.items()}, sub(fx, "step0/param"), **TOL)
-    assert_dict_close("final", {k: v.detach().numpy() for k, v in vae.p.items()}, sub(fx, "final/param"), **TOL)
+            assert_dict_close("param0", {k: v.detach().numpy() for k, v in vae.p.items()}, sub(fx, "step0/param"), **PTOL(1e-3, 1))
+    assert_dict_close("final", {k: v.detach().numpy() for k, v in vae.p.items()}, sub(fx, "final/param"), **PTOL(1e-3, 3))
     if g == 4:
         m = {n: t.numpy() for n, t in zip(vae.names, vae.opt.exp_avg)}
         v = {n: t.numpy() for n, t in zip(vae.names, vae.opt.exp_avg_sq)}
@@ -61,7 +70,8 @@ def test_vae_batch_loop():
     vae = O.VAE(_t(sub(fx, "init")), 2)
     losses = [vae.learn(chunks[ci], torch.from_numpy(fx["eps%d" % s])) for s, ci in enumerate(order)]
     assert_close("losses", losses, fx["losses"], **TOL)
-    assert_dict_close("final", {k: v.detach().numpy() for k, v in vae.p.items()}, sub(fx, "final/param"), **TOL)
+    assert_dict_close("final", {k: v.detach().numpy() for k, v in vae.p.items()}, sub(fx, "final/param"),
+                      **PTOL(1e-3, len(order)))
 
 
 def test_lstm_matches_nn_lstm():
