@@ -82,6 +82,7 @@ SIGNATURES = {
     "hhrl_copy2d_group": (_I, [_P, _I, _I, _P]),
     "hhrl_gather_rows": (_I, [_P, _L, _I, _P, _P, _I, _I, _I, _P]),
     "hhrl_fill": (_I, [_P, _L, _F, _P]),
+    "hhrl_randn_fill": (_I, [_P, _L, C.c_ulonglong, C.c_ulonglong, _P]),
     "hhrl_vae_reparam": (_I, [_P, _P, _P, _I, _I, _P]),
     "hhrl_vae_elbo": (_I, [_P, _P, _P, _F, _P, _P, _I, _I, _I, _P]),
     "hhrl_vae_latent_grad": (_I, [_P, _P, _P, _P, _I, _I, _P]),

@@ -175,6 +175,55 @@ __global__ void fill_kernel(float* p, long n, float v) {
   if (idx < n) p[idx] = v;
 }
 
+// Standard normals from a counter-based generator: Philox4x32-10 (Salmon et al., SC'11) keyed by the seed, counter =
+// index of the output quadruple, four uniforms per counter turned into four normals by two Box-Muller pairs.  Element
+// i of the stream depends on (seed, i) only: a fill of n values at offset o equals the same range of one long fill,
+// whatever the grid, so a pool can be refilled piecewise and a run can be repeated from its seed.
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
+  const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+  const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
+  c[1] = (unsigned)p1;
+  c[3] = (unsigned)p0;
+  c[0] = n0;
+  c[2] = n2;
+}
+__device__ __forceinline__ void philox4x32_10(unsigned long long ctr, unsigned long long seed, unsigned (&out)[4]) {
+  unsigned c[4] = {(unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u};
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out[i] = c[i];
+}
+// (0, 1]: never zero, so the logarithm below is finite
+__device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f); }
+__global__ __launch_bounds__(256) void randn_fill_kernel(float* __restrict__ out, long n, unsigned long long seed, unsigned long long offset) {
+  // thread t produces elements 4 t' .. 4 t' + 3 of the STREAM (t' counted from the stream's origin) that fall into
+  // [offset, offset + n)
+  const unsigned long long q0 = offset >> 2;
+  const unsigned long long q = q0 + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned r[4];
+  philox4x32_10(q, seed, r);
+  float z[4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float rad = sqrtf(-2.0f * logf(u01(r[2 * h])));
+    float sn, cs;
+    sincospif(2.0f * u01(r[2 * h + 1]), &sn, &cs);
+    z[2 * h] = rad * cs;
+    z[2 * h + 1] = rad * sn;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned long long i = 4 * q + e;
+    if (i >= offset && i - offset < (unsigned long long)n) out[i - offset] = z[e];
+  }
+}
+
 static int valid_act(int act) { return act >= HHRL_ACT_NONE && act <= HHRL_ACT_SIGMOID; }
 
 }  // namespace hhrl
@@ -413,6 +462,15 @@ int hhrl_fill(float* p, long n, float value, void* stream) {
   ProfScope ps("fill_kernel", as_stream(stream), 0.0, 4.0 * n);
   hipLaunchKernelGGL(fill_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), p, n, value);
   return launch_status("fill_kernel");
+}
+
+int hhrl_randn_fill(float* out, long n, unsigned long long seed, unsigned long long offset, void* stream) {
+  HHRL_REQUIRE(out && n > 0, "randn_fill: null pointer or n <= 0");
+  const unsigned long long quads = ((offset + (unsigned long long)n + 3) >> 2) - (offset >> 2);
+  HHRL_REQUIRE(quads <= 0x7fffffffull * 256ull, "randn_fill: n=%ld too large for one launch", n);
+  ProfScope ps("randn_fill_kernel", as_stream(stream), 0.0, 4.0 * n);
+  hipLaunchKernelGGL(randn_fill_kernel, dim3(ceil_div((long)quads, 256)), dim3(256), 0, as_stream(stream), out, n, seed, offset);
+  return launch_status("randn_fill_kernel");
 }
 
 }  // extern "C"

@@ -169,8 +169,7 @@ class Encoder:
         # initial weights) but hold different lanes: their noise streams are offset by the rank, so the global
         # batch carries independent draws.
         noise_seed = (3407 if seed is None else seed) + 1000003 * self.rank
-        self._rng = torch.Generator(device=self.device)
-        self._rng.manual_seed(noise_seed)
+        self._noise_seed, self._noise_off = int(noise_seed), 0          # position in the device generator's stream
         self._eps_pool = None           # reparameterisation noise is drawn EPS_POOL floats at a time
         self._eps_used = 0
         # static_shards: every rank hands the same shard shape to every learn() call, so the global element
@@ -247,15 +246,23 @@ class Encoder:
         self.func2.fwd(P(w.f1), 128, P(w.f2), 32, M)
         self.func4.fwd(P(w.f2), 32, P(w.dec), 1, M)
 
+    def _randn(self, n: int) -> torch.Tensor:
+        """n standard normals from the library's counter-based device generator (hhrl_randn_fill): the next n
+        elements of this encoder's stream (seed, rank)."""
+        out = torch.empty(n, device=self.device, dtype=torch.float32)
+        check(self._lib.hhrl_randn_fill(P(out), n, self._noise_seed, self._noise_off, _lib.stream_ptr()))
+        self._noise_off += (n + 3) & ~3
+        return out
+
     def _draw_eps(self, B: int, g: int) -> torch.Tensor:
         """[B, g] standard normals (algorithm.py:89) cut from a pool that one
         generator launch refills, so a training step pays no launch for them."""
         n = B * g
         if n > self.EPS_POOL // 4:
-            return torch.randn((B, g), generator=self._rng, device=self.device, dtype=torch.float32)
+            return self._randn(n).view(B, g)
         if self._eps_pool is None or self._eps_used + n > self.EPS_POOL:
             # a fresh tensor each time: slices handed out earlier may still be queued on the stream
-            self._eps_pool = torch.randn(self.EPS_POOL, generator=self._rng, device=self.device, dtype=torch.float32)
+            self._eps_pool = self._randn(self.EPS_POOL)
             self._eps_used = 0
             self._eps_base = self._eps_pool.data_ptr()
         e = self._eps_pool[self._eps_used:self._eps_used + n].view(B, g)
@@ -267,10 +274,10 @@ class Encoder:
         without building a view per step."""
         n = B * g
         if n > self.EPS_POOL // 4:
-            e = torch.randn((B, g), generator=self._rng, device=self.device, dtype=torch.float32)
+            e = self._randn(n).view(B, g)
             return e.data_ptr(), e
         if self._eps_pool is None or self._eps_used + n > self.EPS_POOL:
-            self._eps_pool = torch.randn(self.EPS_POOL, generator=self._rng, device=self.device, dtype=torch.float32)
+            self._eps_pool = self._randn(self.EPS_POOL)
             self._eps_used = 0
             self._eps_base = self._eps_pool.data_ptr()
         ptr = self._eps_base + 4 * self._eps_used
@@ -468,7 +475,7 @@ class Encoder:
         loc_t = torch.as_tensor(loc, dtype=torch.float32).reshape(B, -1).to(self.device).contiguous()
         N = int(loc_t.shape[1])
         if eps is None:
-            eps_t = torch.randn((B, g), generator=self._rng, device=self.device, dtype=torch.float32)
+            eps_t = self._randn(B * g).view(B, g)
         else:
             eps_t = torch.as_tensor(eps, dtype=torch.float32).reshape(B, g).to(self.device).contiguous()
         if self.fused:

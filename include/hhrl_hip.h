@@ -116,6 +116,12 @@ int hhrl_gather_rows(const float* in, long ldi, int n_in, const int* idx, float*
                      void* stream);
 /* p[i] = value */
 int hhrl_fill(float* p, long n, float value, void* stream);
+/* out[i] = element (offset + i) of the standard-normal stream of `seed`, i < n: the draws of `torch.randn_like`
+ * (Encoder.reparameterize, algorithm.py:89) made on the device by a counter-based generator (Philox4x32-10 and
+ * Box-Muller).  An element depends on (seed, offset + i) only: consecutive fills continue one stream, the same
+ * (seed, offset) gives the same values on every run.  The reference's own draws come from torch's global
+ * generator and cannot be reproduced; callers that need given values pass their own eps to the step instead. */
+int hhrl_randn_fill(float* out, long n, unsigned long long seed, unsigned long long offset, void* stream);
 
 /* --------------------------------------------------------------------- VAE
  * z = mean + eps * exp(0.5*logvar)          (Encoder.reparameterize, algorithm.py:87-90;

@@ -40,6 +40,9 @@ def _act(x, act):
     (640, 13, 512, 0), (64, 300, 4, 2), (1, 5, 3, 2), (5, 1, 1, 0),
     # activation and bias gradient inside the backward products: a reduction split over workgroups, odd sizes
     (1500, 70, 33, 3), (64, 301, 37, 2), (33, 7, 65, 1),
+    # enough 64 x 64 output tiles for the double-buffered block kernel: aligned and odd leading dimensions (ldx = K + 3),
+    # partial tiles on both edges, a reduction that ends inside a chunk
+    (1024, 393, 512, 1), (1024, 509, 256, 2), (2048, 128, 400, 1), (1000, 300, 401, 3), (4096, 256, 128, 1),
 ])
 def test_linear_forward_backward(env, M, K, N, act):
     lib, L, dev = env
@@ -590,3 +593,33 @@ def test_mlp3_fused_matches_torch(env, M, K0, N3, act3):
     L.check(lib.hhrl_mlp3_backward_group(descs, 1, M, st))
     scaled_close("dx only", keep[0][7][:, :K0].cpu().numpy(), refs[0][1].numpy(), atol_rel=1e-5)
     assert all(torch.equal(a, b) for a, b in zip(before, keep[0][3]))
+
+
+def test_randn_fill_is_a_reproducible_normal_stream(env):
+    """hhrl_randn_fill: the same (seed, offset) gives the same values, consecutive fills continue one stream whatever
+    their lengths and alignment, other seeds give other values, and the values are standard normal (moments and a
+    Kolmogorov-Smirnov distance over 4 Mi draws; tails beyond 4.5 sigma exist and are finite)."""
+    from scipy import stats
+    lib, L, dev = env
+    st = L.stream_ptr()
+    n = 1 << 22
+
+    def fill(n, seed, off):
+        out = torch.full((n + 8,), 77.0, device=dev)
+        L.check(lib.hhrl_randn_fill(out.data_ptr(), n, seed, off, st))
+        assert torch.all(out[n:] == 77.0), "wrote past the end"
+        return out[:n].cpu().numpy()
+
+    a = fill(n, 3407, 0)
+    assert np.array_equal(a, fill(n, 3407, 0))
+    for off, m in ((0, 5), (5, 1000), (1005, 3), (1008, 4099), (5107, 1)):          # pieces at odd offsets
+        assert np.array_equal(fill(m, 3407, off), a[off:off + m])
+    b = fill(n, 3408, 0)
+    assert not np.array_equal(a, b) and abs(np.corrcoef(a, b)[0, 1]) < 3e-3
+    assert np.all(np.isfinite(a))
+    x = a.astype(np.float64)
+    assert abs(x.mean()) < 3e-3 and abs(x.var() - 1.0) < 5e-3
+    assert abs(stats.skew(x)) < 1e-2 and abs(stats.kurtosis(x)) < 2e-2
+    assert stats.kstest(x[:1 << 20], "norm").statistic < 2.5e-3
+    assert abs(np.corrcoef(x[:-1], x[1:])[0, 1]) < 3e-3                              # neighbours (a Box-Muller pair) uncorrelated
+    assert 20 < np.sum(np.abs(x) > 4.5) < 90                                         # expected 28.5 of 4 Mi
