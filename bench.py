@@ -311,6 +311,36 @@ def inference_latency(enc, device) -> dict:
     return out
 
 
+def scenario_rates(seconds: int = 60) -> dict:
+    """Extra field: the four-intersection scenario (the reference's per-second call cadence, train.py:183-204, on a
+    synthetic transition stream: 4 lights x 8 lanes, Encoder(2, 2), HATD3Triple, WorkerTD3; tools/four_intersections.py)
+    with the reference's one-call-per-lane inference and with the batched calls.  Wall time of `seconds` simulated
+    seconds after a 60-second warm-up that fills the replays and captures the graphs; `learning_path_wall_s` is the
+    host time spent inside the classes (the rest is the synthetic stream itself)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import four_intersections as fi
+    import hhrl_vae_amd.algorithm as A
+    out = {}
+    for batched in (False, True):
+        mcfg, wcfg = fi.make_cfgs(manager_capacity=640, worker_capacity=320)
+        enc, mgr, wrk = A.Encoder(2, 2), A.HATD3Triple(mcfg), A.WorkerTD3(wcfg)
+        st = fi.Stream()
+        fi.run(enc, mgr, wrk, st, 60, batched=batched)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fi.run(enc, mgr, wrk, st, seconds, seed=1, batched=batched)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        path = sum(v for k, v in r.items() if k.startswith("wall_"))
+        out["batched_calls" if batched else "one_call_per_lane"] = {
+            "simulated_seconds": seconds, "wall_s": dt, "simulated_seconds_per_s": seconds / dt, "learning_path_wall_s": path,
+            "manager_updates": r.get("learn_manager"), "worker_updates": r.get("learn_worker"),
+            "encode_calls": r.get("encode"), "decode_calls": r.get("decode"),
+            "wall_learn_manager_s": r.get("wall_learn_manager"), "wall_learn_worker_s": r.get("wall_learn_worker"),
+            "wall_encode_s": r.get("wall_encode"), "wall_decode_s": r.get("wall_decode"), "wall_choose_s": r.get("wall_choose")}
+    return out
+
+
 def pmc_traffic(workload: str, kernel: str, suffix: str = "_hbm_traffic.json", field: str = "hbm_bytes_per_launch"):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary
     of this workload (rocprofv3 FETCH_SIZE / WRITE_SIZE passes, read bytes
@@ -613,6 +643,8 @@ def main() -> None:
             out["dp_one_rank"] = dp_probe
         if world == 1 and not args.no_agents:
             out["inference"] = inference_latency(enc, device)
+            progress("four-intersection scenario")
+            out["scenario"] = scenario_rates()
         if world == 1 and not args.no_cpu_baseline:
             progress("CPU oracle: VAE step")
             out["cpu_baseline"] = cpu_baseline_vae(B, N, g)

@@ -386,7 +386,10 @@ def test_lstm_forward_backward(env, B, T, o, H):
 
 # ------------------------------------------------------------------ grouped / fused entry points
 @pytest.mark.parametrize("B,T,H,obs_dims", [(64, 10, 128, (13, 13, 25)), (33, 4, 32, (5, 29)), (7, 3, 8, (4, 6, 3)),
-                                            (130, 6, 128, (13, 32, 5)), (350, 2, 128, (1, 16, 17, 9, 9, 9, 9, 9, 9))])
+                                            (130, 6, 128, (13, 32, 5)), (350, 2, 128, (1, 16, 17, 9, 9, 9, 9, 9, 9)),
+                                            # several passes per workgroup (an odd number of row groups, a partial last group;
+                                            # both observation widths; one module with more groups than workgroups)
+                                            (1098, 5, 128, (13, 25, 32)), (2001, 3, 128, (13,))])
 def test_lstm_group_matches_torch(env, B, T, H, obs_dims):
     """hhrl_lstm_forward_group / _backward_group: several LSTM modules with different observation
     widths in one call, each against torch.nn.LSTM + Linear."""
