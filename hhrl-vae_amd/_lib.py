@@ -22,7 +22,7 @@ _D = C.c_double
 class LstmDesc(C.Structure):
     """hhrl_lstm_desc of include/hhrl_hip.h."""
     _fields_ = [("obs", _P), ("ldobs", _I), ("o", _I), ("params", _P), ("grads", _P), ("out", _P), ("ldo", _I),
-                ("d_out", _P), ("lddo", _I), ("ws", _P)]
+                ("d_out", _P), ("lddo", _I), ("ws", _P), ("no_backward", _I)]
 
 
 LSTM_GROUP_MAX = 16

@@ -468,25 +468,36 @@ struct SeqFwdInst {
   const float *w_ih_r, *b_ih_r, *b_hh_r;              // reverse direction
   float *x_tm, *gates, *cbuf, *hbuf, *cat, *gates_r, *c_r;
   int ldobs, o;
+  int save;                                           // 0: nobody back-propagates this evaluation; only `cat` is written
 };
-struct SeqFwdGroup { SeqFwdInst in[kMaxInst]; };
+// The launch is one row of workgroups; module m owns workgroups wg0[m] .. wg0[m+1]-1, the first n_rev[m] of them
+// take the reverse direction's step.  Modules whose steps are not saved are cheaper per step and get fewer.
+struct SeqFwdGroup {
+  SeqFwdInst in[kMaxInst];
+  short wg0[kMaxInst + 1], n_rev[kMaxInst];
+  int n;
+};
 
 constexpr int SQ_SLAB = 512 * 33 + 64;                 // one 32-column slab of a [512][.] weight matrix, row stride 33 (+16 per gate)
 template <int OPAD>
-__global__ __launch_bounds__(512) void lstm_seq_forward_kernel(SeqFwdGroup grp, int B, int T, int chunks, int gx_r) {
+__global__ __launch_bounds__(512) void lstm_seq_forward_kernel(SeqFwdGroup grp, int B, int T, int chunks) {
   constexpr int H = SQ_H, G = SQ_G, LD = H + 4;           // LD * 4 bytes is a multiple of 16
   // dynamic LDS: the weight slab of the prologue, then the window's observations [T][4][OPAD] of the four rows
   extern __shared__ __attribute__((aligned(16))) float dyn[];
   float* xall = dyn + SQ_SLAB;
   __shared__ __attribute__((aligned(16))) float hs[2][4][LD];     // h_{t-1} / h_t of the four rows
   __shared__ float xg[8][4][SQ_XG];
-  const SeqFwdInst& g = grp.in[blockIdx.z];
+  int mod = 0;
+  while (mod + 1 < grp.n && (int)blockIdx.x >= grp.wg0[mod + 1]) ++mod;
+  const SeqFwdInst& g = grp.in[mod];
+  const int wg = blockIdx.x - grp.wg0[mod], gx_all = grp.wg0[mod + 1] - grp.wg0[mod], gx_r = grp.n_rev[mod];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int o = g.o;
   const long BH = (long)B * H;
+  const bool save = g.save != 0;
 
-  if ((int)blockIdx.x < gx_r) {
+  if (wg < gx_r) {
     // ---- reverse direction: one step from the zero state on x[T-1]; thread = gate column.  These workgroups come
     // first in dispatch order and are few (each takes several groups of rows): they are done within microseconds.
     float (*pre_r)[G + 4] = reinterpret_cast<float (*)[G + 4]>(dyn);
@@ -496,7 +507,7 @@ __global__ __launch_bounds__(512) void lstm_seq_forward_kernel(SeqFwdGroup grp, 
     const float bias = g.b_ih_r[tid] + g.b_hh_r[tid];
     const int xr = tid / OPAD, xc = tid - xr * OPAD;
     const int row = tid >> 7, unit = tid & 127;
-    for (int chunk = blockIdx.x; chunk < chunks; chunk += gx_r) {
+    for (int chunk = wg; chunk < chunks; chunk += gx_r) {
       const int r0 = chunk * 4;
       if (tid < 4 * OPAD)
         xall[xr * OPAD + xc] = (xc < o && r0 + xr < B) ? g.obs[(long)(r0 + xr) * g.ldobs + (long)(T - 1) * o + xc] : 0.f;
@@ -514,17 +525,19 @@ __global__ __launch_bounds__(512) void lstm_seq_forward_kernel(SeqFwdGroup grp, 
         const float gf = sigmoidf_(pre_r[row][H + unit]);
         const float gg = tanhf(pre_r[row][2 * H + unit]);
         const float go = sigmoidf_(pre_r[row][3 * H + unit]);
-        float* gr = g.gates_r + (long)(r0 + row) * G;
-        gr[unit] = gi; gr[H + unit] = gf; gr[2 * H + unit] = gg; gr[3 * H + unit] = go;
         const float c = gi * gg;                       // the cell state before the step is zero
-        g.c_r[(long)(r0 + row) * H + unit] = c;
+        if (save) {
+          float* gr = g.gates_r + (long)(r0 + row) * G;
+          gr[unit] = gi; gr[H + unit] = gf; gr[2 * H + unit] = gg; gr[3 * H + unit] = go;
+          g.c_r[(long)(r0 + row) * H + unit] = c;
+        }
         g.cat[(long)(r0 + row) * 2 * H + H + unit] = go * tanhf(c);
       }
       __syncthreads();
     }
     return;
   }
-  const int bx = blockIdx.x - gx_r, gx_f = gridDim.x - gx_r;
+  const int bx = wg - gx_r, gx_f = gx_all - gx_r;
 
   LSTM_STAMP(0, 0);
   // ---- forward direction.  Matrix role: lane = (gate, unit of the wave); cell role: lane = (row, unit of the wave)
@@ -548,7 +561,7 @@ __global__ __launch_bounds__(512) void lstm_seq_forward_kernel(SeqFwdGroup grp, 
         const int xc = e % OPAD, rt = e / OPAD, xr = rt & 3, t = rt >> 2;
         if (e < T * 4 * OPAD) {
           xall[e] = v[u];
-          if (xc < o && r0 + xr < B) g.x_tm[((long)t * B + r0 + xr) * o + xc] = v[u];
+          if (save && xc < o && r0 + xr < B) g.x_tm[((long)t * B + r0 + xr) * o + xc] = v[u];
         }
       }
     }
@@ -603,7 +616,7 @@ __global__ __launch_bounds__(512) void lstm_seq_forward_kernel(SeqFwdGroup grp, 
     const int r0 = chunk * 4;
     const bool valid = r0 + crow < B;
     if (chunk != bx) stage_x(r0);                          // (the first group's were requested with the weights)
-    if (valid) {                                           // the zero slot of the state buffers
+    if (valid && save) {                                   // the zero slot of the state buffers
       g.hbuf[(long)(r0 + crow) * H + cu] = 0.f;
       g.cbuf[(long)(r0 + crow) * H + cu] = 0.f;
     }
@@ -683,13 +696,15 @@ __global__ __launch_bounds__(512) void lstm_seq_forward_kernel(SeqFwdGroup grp, 
       if (t == 1) LSTM_STAMP(0, 3);
       hs[cur ^ 1][crow][cu] = hv;
       if (valid) {
-        p_gate[0] = gi; p_gate[H] = gf; p_gate[2 * H] = gg; p_gate[3 * H] = go;
-        *p_c = c;
-        *p_h = hv;
+        if (save) {
+          p_gate[0] = gi; p_gate[H] = gf; p_gate[2 * H] = gg; p_gate[3 * H] = go;
+          *p_c = c;
+          *p_h = hv;
+          p_gate += (long)B * G;
+          p_c += BH;
+          p_h += BH;
+        }
         if (t == T - 1) g.cat[(long)(r0 + crow) * 2 * H + cu] = hv;
-        p_gate += (long)B * G;
-        p_c += BH;
-        p_h += BH;
       }
       if (t == 1) LSTM_STAMP(0, 4);
       lds_barrier();
@@ -1063,29 +1078,46 @@ int hhrl_lstm_forward_group(const hhrl_lstm_desc* d, int n, int B, int T, int H,
     for (int i = 0; i < n; ++i) {
       const float* const* p = d[i].params;
       sg.in[i] = SeqFwdInst{d[i].obs, p[0], p[1], p[2], p[3], p[4], p[6], p[7], w[i].x_tm, w[i].gates, w[i].cbuf, w[i].hbuf,
-                            w[i].cat, w[i].gates_r, w[i].c_r, d[i].ldobs, d[i].o};
+                            w[i].cat, w[i].gates_r, w[i].c_r, d[i].ldobs, d[i].o, d[i].no_backward ? 0 : 1};
     }
     const int chunks = ceil_div(B, 4);
     // One round of the 256 CUs for the forward and the reverse workgroups of all modules (243 in all: a workgroup that
     // has to wait for a CU starts when a forward workgroup ends and doubles the launch).  A reverse workgroup runs
     // ONE step per group of four rows against T for a forward one, so a ninth of a module's workgroups keeps pace
     // (nine modules at batch 1024: 24 + 3 per module instead of 22 + 5, 225 -> 200 us).
-    const int per = 243 / n > 2 ? 243 / n : 2;
-    int gx_r = per / 9 > 1 ? per / 9 : 1;
-    int gx_f = per - gx_r;
-    if (gx_f > chunks) gx_f = chunks;
-    if (gx_r > chunks) gx_r = chunks;
-    const dim3 grid(gx_r + gx_f, 1, n);
+    // Workgroups per module.  A module whose steps are not saved (no_backward) issues no stores inside its time loop, but
+    // its steps are not measurably shorter (the stores drain under the products): on whole HATD3Triple updates at batch
+    // 1024 equal shares were the fastest (shares 0.55 / 0.65 / 0.76 / 0.9 / 1.0 of a saving module's workgroups: 1.268 /
+    // 1.245 / 1.220 / 1.208 / 1.212 ms).  HHRL_LSTM_NOSAVE_SHARE sets another share for sweeps.
+    static const double nosave_w = [] { const char* e = getenv("HHRL_LSTM_NOSAVE_SHARE"); return e ? atof(e) : 1.0; }();
+    double wsum = 0.0;
+    for (int i = 0; i < n; ++i) wsum += sg.in[i].save ? 1.0 : nosave_w;
+    sg.n = n;
+    sg.wg0[0] = 0;
+    for (int i = 0; i < n; ++i) {
+      int per = (int)(243.0 * (sg.in[i].save ? 1.0 : nosave_w) / wsum);
+      if (per < 2) per = 2;
+      int gx_r = per / 9 > 1 ? per / 9 : 1;
+      int gx_f = per - gx_r;
+      if (gx_f > chunks) gx_f = chunks;
+      if (gx_r > chunks) gx_r = chunks;
+      sg.n_rev[i] = (short)gx_r;
+      sg.wg0[i + 1] = (short)(sg.wg0[i] + gx_r + gx_f);
+    }
+    const dim3 grid(sg.wg0[n], 1, 1);
     const size_t lds_fwd = 4 * (size_t)(SQ_SLAB + T * 4 * 32);
     HHRL_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(lstm_seq_forward_kernel<16>), (int)lds_fwd, "lstm"));
     HHRL_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(lstm_seq_forward_kernel<32>), (int)lds_fwd, "lstm"));
     ProfScope ps("lstm_seq_forward_kernel", st, 2.0 * B * G * ((double)T * (H + omax) + omax) * n,
                  4.0 * n * ((double)B * T * (G + 2.0 * H + 2.0 * omax) + (double)G * (H + 2.0 * omax)));
 #ifdef HHRL_STAMPS
-    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_lstm_stamp_wg), &gx_r, sizeof(int), 0, hipMemcpyHostToDevice, st);
+    {
+      const int first_fwd = sg.n_rev[0];
+      (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_lstm_stamp_wg), &first_fwd, sizeof(int), 0, hipMemcpyHostToDevice, st);
+    }
 #endif
-    if (omax <= 16) hipLaunchKernelGGL(lstm_seq_forward_kernel<16>, grid, dim3(512), lds_fwd, st, sg, B, T, chunks, gx_r);
-    else hipLaunchKernelGGL(lstm_seq_forward_kernel<32>, grid, dim3(512), lds_fwd, st, sg, B, T, chunks, gx_r);
+    if (omax <= 16) hipLaunchKernelGGL(lstm_seq_forward_kernel<16>, grid, dim3(512), lds_fwd, st, sg, B, T, chunks);
+    else hipLaunchKernelGGL(lstm_seq_forward_kernel<32>, grid, dim3(512), lds_fwd, st, sg, B, T, chunks);
     HHRL_TRY(launch_status("lstm_seq_forward_kernel"));
   }
   if (!seq) {
@@ -1353,6 +1385,7 @@ int hhrl_lstm_forward(const float* obs, int ldobs, const float* const* params, f
   d.out = out; d.ldo = ldo;
   d.d_out = nullptr; d.lddo = 0;
   d.ws = ws;
+  d.no_backward = 0;
   return hhrl_lstm_forward_group(&d, 1, B, T, H, stream);
 }
 
@@ -1364,6 +1397,7 @@ int hhrl_lstm_backward(const float* const* params, const float* d_out, int lddo,
   d.out = nullptr; d.ldo = 0;
   d.d_out = d_out; d.lddo = lddo;
   d.ws = ws;
+  d.no_backward = 0;
   return hhrl_lstm_backward_group(&d, 1, B, T, H, stream);
 }
 

@@ -169,8 +169,9 @@ def _lstm_descs(items, forward: bool):
         d.params = C.cast(l.params, C.c_void_p)
         d.grads = C.cast(l.grads, C.c_void_p) if l.grads is not None else None
         if forward:
-            _, obs, ldobs, out, ldo, ws = it
+            _, obs, ldobs, out, ldo, ws = it[:6]
             d.obs, d.ldobs, d.out, d.ldo = obs, ldobs, out, ldo
+            d.no_backward = 1 if len(it) > 6 and it[6] else 0
         else:
             _, d_out, lddo, ws = it
             d.d_out, d.lddo = d_out, lddo
@@ -179,8 +180,9 @@ def _lstm_descs(items, forward: bool):
 
 
 def lstm_forward_group(items, B: int) -> None:
-    """items: [(BiLstm, obs_ptr, ldobs, out_ptr, ldo, workspace)]: LSTM modules sharing T and H,
-    evaluated on B rows each, every stage one launch for the whole group."""
+    """items: [(BiLstm, obs_ptr, ldobs, out_ptr, ldo, workspace[, no_backward])]: LSTM modules sharing T and H,
+    evaluated on B rows each, every stage one launch for the whole group.  no_backward: nobody back-propagates
+    this evaluation (a target network, a feature whose gradient is not wanted): its per-step states are not saved."""
     lib = _lib.load()
     T, H = items[0][0].T, items[0][0].H
     for it in items:

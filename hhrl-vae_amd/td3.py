@@ -85,10 +85,10 @@ class ActorNet:
             w = self._work[B] = _ActorWork(self, B, self.dev)
         return w
 
-    def lstm_item(self, B: int, obs: int, ld_obs: int):
+    def lstm_item(self, B: int, obs: int, ld_obs: int, no_backward: bool = False):
         """This actor's LSTM evaluation as an entry of a grouped launch (ops.lstm_forward_group)."""
         w = self.work(B)
-        return (self.lstm, obs, ld_obs, P(w.xin), self.d_in, w.lstm_ws)
+        return (self.lstm, obs, ld_obs, P(w.xin), self.d_in, w.lstm_ws, no_backward)
 
     def lstm_bwd_item(self, B: int):
         w = self.work(B)
@@ -124,12 +124,16 @@ class ActorNet:
         self.mlp3.desc(d, w.x, w.ldx, out, ld_out, P(w.h1), P(w.h2))
 
     def forward(self, B: int, obs: int, ld_obs: int, goal: Optional[int], ld_goal: int, out: int, ld_out: int,
-                lstm_done: bool = False, inputs_done: bool = False) -> None:
+                lstm_done: bool = False, inputs_done: bool = False, no_backward: bool = False) -> None:
         """lstm_done: the LSTM feature was already produced by a grouped launch built from lstm_item();
-        inputs_done: stage_inputs() was already flushed for these rows."""
+        inputs_done: stage_inputs() was already flushed for these rows; no_backward: backward() will not
+        follow on this evaluation (the LSTM then saves none of its steps)."""
         w = self.work(B)
         if self.lstm is not None and not lstm_done:
-            self.lstm.fwd(obs, ld_obs, P(w.xin), self.d_in, w.lstm_ws, B)
+            if no_backward:
+                ops.lstm_forward_group([self.lstm_item(B, obs, ld_obs, True)], B)
+            else:
+                self.lstm.fwd(obs, ld_obs, P(w.xin), self.d_in, w.lstm_ws, B)
         if not inputs_done:
             cq = ops.CopyQueue(B)
             self.stage_inputs(cq, B, obs, ld_obs, goal, ld_goal)
@@ -232,12 +236,12 @@ class CriticNet:
         else:
             ops.copy2d(o_ptr, o_ld, P(w.xu, col), self.D, B, s.o)
 
-    def feature_item(self, k: int, B: int, o_ptr: int, o_ld: int):
+    def feature_item(self, k: int, B: int, o_ptr: int, o_ld: int, no_backward: bool = False):
         """Stream k's LSTM evaluation as an entry of a grouped launch (streams without an LSTM: None)."""
         if self.lstms[k] is None:
             return None
         w = self.work(B)
-        return (self.lstms[k], o_ptr, o_ld, P(w.xu, self.feat_cols[k]), self.D, w.lstm_ws[k])
+        return (self.lstms[k], o_ptr, o_ld, P(w.xu, self.feat_cols[k]), self.D, w.lstm_ws[k], no_backward)
 
     def lstm_bwd_item(self, k: int, B: int):
         if self.lstms[k] is None:
@@ -809,8 +813,9 @@ class TD3Learner:
         c, cw = self.critic, self.critic.work(B)
         # every LSTM that depends only on the minibatch goes into one grouped evaluation: the target actors'
         # and the target critic's on the next observations, the critic's on the current ones
-        items = [a.lstm_item(B, next_obs[k][0], W) for k, a in enumerate(self.actor_targets) if a.lstm is not None]
-        items += [ct.feature_item(k, B, next_obs[k][0], W) for k in range(n_str)]
+        # (the target networks' evaluations are never back-propagated, algorithm.py:785: their steps are not saved)
+        items = [a.lstm_item(B, next_obs[k][0], W, True) for k, a in enumerate(self.actor_targets) if a.lstm is not None]
+        items += [ct.feature_item(k, B, next_obs[k][0], W, True) for k in range(n_str)]
         items += [c.feature_item(k, B, obs[k][0], W) for k in range(n_str)]
         self._lstm_forward(items, B)
         # every piece of a network input that is a plain column range of the sampled rows: one launch
@@ -891,7 +896,8 @@ class TD3Learner:
         # -- delayed policy step: :1353-1366 / 811-838
         if policy:
             # LSTM features under the updated critic weights, and every actor's LSTM, in one grouped evaluation
-            items = [c.feature_item(k, B, obs[k][0], W) for k in range(n_str)]
+            # (the policy step differentiates Q1 with respect to the actions only: the critic's LSTMs save nothing)
+            items = [c.feature_item(k, B, obs[k][0], W, True) for k in range(n_str)]
             items += [a.lstm_item(B, obs[j][0], W) for j, a in enumerate(self.actors) if a.lstm is not None]
             self._lstm_forward(items, B)
             # joint action written straight into the critic input: layer k of every actor in one launch
@@ -911,7 +917,7 @@ class TD3Learner:
                 self._allreduce(a.opt.g)
                 a.opt.step_dev(P(st.hyper[1 + i]), self.actor_targets[i].params, fam.tau)
                 if n + 1 < len(order):                # later actors see this actor's new policy
-                    a.forward(B, obs[i][0], W, goal, W, P(cw.xu, c.act_cols[i]), c.D, inputs_done=True)
+                    a.forward(B, obs[i][0], W, goal, W, P(cw.xu, c.act_cols[i]), c.D, inputs_done=True, no_backward=True)
 
     @staticmethod
     def _actors_forward(nets, B: int, outs) -> None:
@@ -993,7 +999,7 @@ class TD3Learner:
         if gd:
             hv[:, s.width:] = np.asarray(goal, dtype=np.float32).reshape(n, gd)
         d_in.copy_(h_in, non_blocking=True)
-        run = lambda: self.actors[k].forward(n, P(d_in), wid, P(d_in, s.width) if gd else None, wid, P(d_out), a)
+        run = lambda: self.actors[k].forward(n, P(d_in), wid, P(d_in, s.width) if gd else None, wid, P(d_out), a, no_backward=True)
         if io["graph"] is not None:
             io["graph"].replay()
         elif self.use_graph and self.actors[k].lstm is not None and io["calls"] >= 2:

@@ -304,6 +304,10 @@ typedef struct {
   const float* d_out;          /* backward: [B,H], leading dimension lddo (equal for all instances) */
   int lddo;
   float* ws;                   /* hhrl_lstm_workspace_floats(B,T,o,H) floats per instance */
+  int no_backward;             /* forward: nonzero = this evaluation will not be back-propagated (a target network under
+                                * torch.no_grad, algorithm.py:785-796; the critic's streams on a policy step, :820-821, whose
+                                * gradient is taken w.r.t. the actions only): the per-step gates, cell and hidden states are
+                                * then not written to ws, and hhrl_lstm_backward_group must not follow on it */
 } hhrl_lstm_desc;
 int hhrl_lstm_forward_group(const hhrl_lstm_desc* descs, int n, int B, int T, int H, void* stream);
 int hhrl_lstm_backward_group(const hhrl_lstm_desc* descs, int n, int B, int T, int H, void* stream);

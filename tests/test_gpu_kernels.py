@@ -434,6 +434,48 @@ def test_lstm_group_matches_torch(env, B, T, H, obs_dims):
             scaled_close("grad[%d] %s" % (i, k), gdev.cpu().numpy(), want.numpy(), atol_rel=1e-5)
 
 
+@pytest.mark.parametrize("B", [64, 1098])
+def test_lstm_forward_without_saved_steps(env, B):
+    """hhrl_lstm_desc.no_backward: modules flagged that way give bit for bit the output of an unflagged evaluation
+    and leave their workspace alone apart from the fc input (the per-step gates, cell and hidden states and the
+    time-major observations are not written); unflagged modules of the same launch are unaffected, whatever share
+    of the launch's workgroups each kind gets."""
+    lib, L, dev = env
+    T, H, obs_dims, flags = 10, 128, (13, 25, 13, 32, 7), (1, 0, 1, 1, 0)
+    n = len(obs_dims)
+    g = torch.Generator().manual_seed(B)
+    r = lambda *s: (torch.randn(*s, generator=g) * 0.3).to(dev)
+    st = L.stream_ptr()
+    mods = []
+    for o in obs_dims:
+        ps = [r(4 * H, o), r(4 * H, H), r(4 * H), r(4 * H), r(4 * H, o), r(4 * H, H), r(4 * H), r(4 * H), r(H, 2 * H), r(H)]
+        mods.append((o, ps, (C.c_void_p * 10)(*[p.data_ptr() for p in ps]), r(B, T * o + 2)))
+
+    def run(flagged):
+        descs, keep = (L.LstmDesc * n)(), []
+        for i, (o, ps, parr, obs) in enumerate(mods):
+            ws = torch.full((lib.hhrl_lstm_workspace_floats(B, T, o, H),), 7.0, device=dev)
+            out = torch.zeros(B, H, device=dev)
+            d = descs[i]
+            d.obs, d.ldobs, d.o, d.params = obs.data_ptr(), T * o + 2, o, C.cast(parr, C.c_void_p)
+            d.out, d.ldo, d.ws, d.no_backward = out.data_ptr(), H, ws.data_ptr(), (flags[i] if flagged else 0)
+            keep.append((ws, out))
+        L.check(lib.hhrl_lstm_forward_group(descs, n, B, T, H, st))
+        torch.cuda.synchronize()
+        return keep
+
+    full, part = run(False), run(True)
+    for i in range(n):
+        assert torch.equal(full[i][1], part[i][1]), "module %d: output differs" % i
+        if flags[i]:
+            untouched = int((part[i][0] == 7.0).sum())
+            assert untouched >= part[i][0].numel() - 2 * B * H, "module %d: %d of %d workspace floats left alone" % (
+                i, untouched, part[i][0].numel())
+            assert untouched < part[i][0].numel(), "the fc input must have been written"
+        else:
+            assert torch.equal(full[i][0], part[i][0]), "module %d: saved steps differ" % i
+
+
 def test_lstm_group_argument_errors(env):
     lib, L, dev = env
     descs = (L.LstmDesc * 1)()
