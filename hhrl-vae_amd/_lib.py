@@ -90,6 +90,7 @@ SIGNATURES = {
     "hhrl_vae_train_step": (_I, [_P, _P, _P, _L, _P, _P, _I, _I, _I, _F, _P, _P, _P]),
     "hhrl_vae_train_step_noalloc": (_I, [_P, _P, _P, _L, _P, _P, _I, _I, _I, _F, _P, _P]),
     "hhrl_vae_learn_step": (_I, [_P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _F, _D, _D, _D, _D, _I, _P, _P, _P]),
+    "hhrl_vae_learn_steps": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _I, _D, _D, _D, _D, _I, _P, _P, _P]),
     "hhrl_vae_encode": (_I, [_P, _P, _L, _P, _P, _I, _I, _I, _P, _I, _P]),
     "hhrl_vae_decode": (_I, [_P, _P, _L, _P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
     "hhrl_td3_smooth_action": (_I, [_P, _I, _P, _P, _I, _I, _I, _P]),

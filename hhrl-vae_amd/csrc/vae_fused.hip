@@ -2879,6 +2879,21 @@ int hhrl_vae_learn_step(float* params, float* grads, float* m, float* v, const l
   return vae_step_impl(params, grads, m, v, &k, offsets, n_flat, data, eps, B, N, g, recon_scale, loss, ws, stream);
 }
 
+int hhrl_vae_learn_steps(float* params, float* grads, float* m, float* v, const long* offsets, long n_flat, int n_steps,
+                         const float* const* data, const float* const* eps, const int* B, const int* N, int g, double lr,
+                         double beta1, double beta2, double adam_eps, int first_step, float* const* loss, float* const* ws,
+                         void* stream) {
+  HHRL_REQUIRE(m && v && data && eps && B && N && loss && ws, "vae_learn_steps: null pointer");
+  HHRL_REQUIRE(n_steps >= 1 && first_step >= 1, "vae_learn_steps: n_steps=%d first_step=%d", n_steps, first_step);
+  for (int k = 0; k < n_steps; ++k) {
+    HHRL_REQUIRE(B[k] > 0 && N[k] > 0, "vae_learn_steps: step %d: B=%d N=%d", k, B[k], N[k]);
+    const AdamK ak = make_adam_k(lr, beta1, beta2, adam_eps, first_step + k, 1.0);
+    const float scale = (float)(1.0 / ((double)B[k] * (double)N[k]));
+    HHRL_TRY(vae_step_impl(params, grads, m, v, &ak, offsets, n_flat, data[k], eps[k], B[k], N[k], g, scale, loss[k], ws[k], stream));
+  }
+  return HHRL_OK;
+}
+
 // ---------------------------------------------------------------- a training step that allocates nothing
 // For callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
 // harnesses that forbid it): hhrl_vae_train_step with its workspace in a file-scope device array instead of

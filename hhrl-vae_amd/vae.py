@@ -403,6 +403,53 @@ class Encoder:
                 self.opt.step()                                         # :106
         return float(loss.item()) if sync else loss
 
+    def learn_many(self, chunks, eps_list=None):
+        """`learn(chunk, sync=False)` for every chunk of a list, in order, with ONE library call per group of
+        chunks (hhrl_vae_learn_steps): the loop of VAE_train.py:65-68, whose 64-lane steps take less GPU time than
+        a Python call costs.  chunks: fp32 CUDA tensors [B, N, 2] (vae_train.prepare_chunks); eps_list: optional
+        noise per chunk.  Returns the losses as device scalars, valid until LOSS_RING further steps have run.
+        Single device, fused path only; anything else falls back to one learn() per chunk."""
+        import ctypes
+        chunks = list(chunks)
+        if self.group is not None or not self.fused or not all(
+                isinstance(c, torch.Tensor) and c.is_cuda and c.dtype == torch.float32 and c.dim() == 3 and c.shape[-1] == 2
+                and c.shape[0] > 0 and c.shape[1] > 0 and c.is_contiguous() for c in chunks):
+            return [self.learn(c, eps=None if eps_list is None else eps_list[i], sync=False) for i, c in enumerate(chunks)]
+        lib, g, o = self._lib, self.goal_dim, self.opt
+        out = []
+        group = self.LOSS_RING - 1
+        for lo in range(0, len(chunks), group):
+            part = chunks[lo:lo + group]
+            n = len(part)
+            xs, es, Bs, Ns = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_int * n)(), (ctypes.c_int * n)()
+            ls, wss = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
+            keep = []
+            for k, x in enumerate(part):
+                B, N = int(x.shape[0]), int(x.shape[1])
+                if eps_list is None:
+                    e_ptr, e = self._draw_eps_ptr(B, g)
+                else:
+                    e = torch.as_tensor(eps_list[lo + k], dtype=torch.float32).to(self.device).contiguous()
+                    if tuple(e.shape) != (B, g):
+                        raise ValueError("eps must be [%d, %d], got %s" % (B, g, tuple(e.shape)))
+                    e_ptr = P(e)
+                ws = self._fused_ws.get((B, N))
+                if ws is None:
+                    if len(self._fused_ws) > 64:
+                        self._fused_ws.clear()
+                    ws = self._fused_ws[(B, N)] = ops.dev_zeros(lib.hhrl_vae_workspace_floats(B, N, g, self.layout.size),
+                                                                device=self.device)
+                self._next_loss_slot()
+                xs[k], es[k], Bs[k], Ns[k], ls[k], wss[k] = P(x), e_ptr, B, N, self._loss_ptrs[self._loss_slot], P(ws)
+                out.append(self._loss_scalars[self._loss_slot])
+                keep.append((x, e, ws))
+            check(lib.hhrl_vae_learn_steps(self.params.base_ptr, o.g.base_ptr, o.m.base_ptr, o.v.base_ptr, self._offsets,
+                                           self.layout.size, n, xs, es, Bs, Ns, g, o.lr, o.beta1, o.beta2, o.eps,
+                                           o.step_count + 1, ls, wss, _lib.stream_ptr()))
+            o.step_count += n
+            self._keep = keep
+        return out
+
     # ------------------------------------------------------------ inference
     def _encode_dev(self, cars: torch.Tensor, lane_start: Optional[torch.Tensor], B: int, N: int) -> torch.Tensor:
         out = ops.dev_empty(B, 2 * self.goal_dim, device=self.device)

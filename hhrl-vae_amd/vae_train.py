@@ -59,27 +59,43 @@ def train_one_pass(encoder: Encoder, chunks: Iterable, eps_list: Optional[Sequen
     the device is not drained after every step (the reference's `loss.item()`
     at algorithm.py:107 forces that)."""
     losses: List[float] = []
-    pending = []
-    sync_every = min(sync_every, encoder.LOSS_RING - 1)     # device losses live in a ring of that many slots
-    for step, data in enumerate(chunks):
-        eps = None if eps_list is None else eps_list[step]
-        if sync_every <= 1:
-            loss = encoder.learn(data, eps=eps)
+    # device losses live in a ring of LOSS_RING slots, and two groups are in flight below
+    sync_every = min(sync_every, (encoder.LOSS_RING - 1) // 2)
+    if sync_every <= 1:
+        for step, data in enumerate(chunks):
+            loss = encoder.learn(data, eps=None if eps_list is None else eps_list[step])
             losses.append(loss)
             if on_step:
                 on_step(step, loss)
+        return losses
+
+    def fetch(ts):
+        import torch
+        # one device-to-host copy for the group (a .item() per loss is a synchronous copy each: 15 us per step)
+        for v in torch.stack(list(ts)).tolist():
+            losses.append(float(v))
+            if on_step:
+                on_step(len(losses) - 1, losses[-1])
+
+    # Groups of sync_every steps; the losses of a group are read only after the NEXT group has been enqueued, so the
+    # device never runs dry while the host reads them (reading right after a group drains the queue: 66 instead
+    # of 50 us per step on the 64-lane chunks of the reference's job).  A group is one library call where the
+    # encoder offers it (learn_many), else one learn() per chunk.
+    chunks = list(chunks)
+    many = getattr(encoder, "learn_many", None)
+    prev = None
+    for lo in range(0, len(chunks), sync_every):
+        part = chunks[lo:lo + sync_every]
+        eps = None if eps_list is None else eps_list[lo:lo + len(part)]
+        if many is not None:
+            cur = many(part, eps)
         else:
-            pending.append(encoder.learn(data, eps=eps, sync=False))
-            if len(pending) >= sync_every:
-                for t in pending:
-                    losses.append(float(t.item()))
-                    if on_step:
-                        on_step(len(losses) - 1, losses[-1])
-                pending = []
-    for t in pending:
-        losses.append(float(t.item()))
-        if on_step:
-            on_step(len(losses) - 1, losses[-1])
+            cur = [encoder.learn(c, eps=None if eps is None else eps[i], sync=False) for i, c in enumerate(part)]
+        if prev is not None:
+            fetch(prev)
+        prev = cur
+    if prev is not None:
+        fetch(prev)
     return losses
 
 

@@ -176,6 +176,18 @@ int hhrl_vae_learn_step(float* params, float* grads, float* m, float* v, const l
                         double lr, double beta1, double beta2, double adam_eps, int step,
                         float* loss, float* ws, void* stream);
 
+/* n_steps consecutive hhrl_vae_learn_step calls in ONE library call: the chunk loop of the reference's
+ * training script (VAE_train.py:65-68: one optimizer step per chunk of <= 64 lanes, chunks of different car
+ * counts) without a return to the host language between steps -- at that chunk size the host's per-call cost
+ * exceeds the step's GPU time.  Step k trains on data[k] = [B[k], N[k], 2] with noise eps[k] = [B[k], g] and
+ * workspace ws[k] (hhrl_vae_workspace_floats(B[k], N[k], g, n_flat) floats; steps of one shape may share one),
+ * divides its squared error by B[k]*N[k] (nn.MSELoss, algorithm.py:84, 102), takes Adam step number
+ * first_step + k and writes its loss to loss[k].  The pointer arrays are host arrays of device pointers. */
+int hhrl_vae_learn_steps(float* params, float* grads, float* m, float* v, const long* offsets, long n_flat, int n_steps,
+                         const float* const* data, const float* const* eps, const int* B, const int* N, int g,
+                         double lr, double beta1, double beta2, double adam_eps, int first_step,
+                         float* const* loss, float* const* ws, void* stream);
+
 /* hhrl_vae_train_step for callers that CANNOT ALLOCATE device memory (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and
  * results as hhrl_vae_train_step (bit for bit) without `ws`: the workspace is a device array built into the

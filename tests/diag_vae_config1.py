@@ -36,7 +36,13 @@ for g in (2, 4, 8, 16):
     train_one_pass(enc, dev_chunks, sync_every=64)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print("g=%d device-resident chunks: %.1f us/step" % (g, 1e6 * dt / len(chunks)))
+    print("g=%d device-resident chunks, groups of 64 steps per library call: %.1f us/step" % (g, 1e6 * dt / len(chunks)))
+    t0 = time.perf_counter()
+    pend = [enc.learn(c, sync=False) for c in dev_chunks]
+    last = pend[-1].item()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("g=%d device-resident chunks, one learn() per chunk: %.1f us/step" % (g, 1e6 * dt / len(chunks)))
 shapes = O.vae_param_shapes(4)
 vae = O.VAE({k: torch.from_numpy(v) for k, v in gen.gen_state(shapes, 1).items()}, 4)
 sample = chunks[:60]

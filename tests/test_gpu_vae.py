@@ -120,6 +120,29 @@ def test_vae_train_all_converts_chunks_once(tmp_path):
             assert os.path.exists(os.path.join(str(tmp_path), "encoder_dim_%d%s" % (g, suf)))
 
 
+def test_vae_learn_many_equals_one_call_per_chunk():
+    """Encoder.learn_many (hhrl_vae_learn_steps: a group of chunks per library call) takes exactly the steps of
+    learn() chunk by chunk: ragged chunk shapes, more chunks than the loss ring holds, injected noise and the
+    encoder's own; losses, parameters and Adam state bit for bit."""
+    from hhrl_vae_amd.algorithm import Encoder
+    rs = np.random.RandomState(11)
+    shapes = [(64, 7), (64, 1), (6, 17), (64, 30), (1, 3), (33, 12)] * 50               # 300 chunks > LOSS_RING
+    chunks = [torch.from_numpy(rs.uniform(0, 1, size=(b, n, 2)).astype(np.float32)).cuda() for b, n in shapes]
+    for inject in (False, True):
+        a, b = Encoder(2, 4, seed=3), Encoder(2, 4, seed=3)
+        eps = [rs.standard_normal((c.shape[0], 4)).astype(np.float32) for c in chunks] if inject else None
+        la = [a.learn(c, eps=None if eps is None else eps[i], sync=False).item() for i, c in enumerate(chunks)]
+        lb = []
+        for lo in range(0, len(chunks), 100):                     # fetched in groups, as the training loop does
+            lb += [t.item() for t in b.learn_many(chunks[lo:lo + 100], None if eps is None else eps[lo:lo + 100])]
+        assert la == lb
+        assert a.opt.step_count == b.opt.step_count == len(chunks)
+        sa, sb = a.state_dict(), b.state_dict()
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), k
+        assert torch.equal(a.opt.m.data, b.opt.m.data) and torch.equal(a.opt.v.data, b.opt.v.data)
+
+
 def test_reference_training_script_body_runs_unchanged(tmp_path):
     """The train-mode body of the reference's script (VAE_train.py:52-69) with only its import swapped to
     `hhrl_vae_amd.algorithm.Encoder`: state log read from disk in the script's own format, chunks of 64,
