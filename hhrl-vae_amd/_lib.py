@@ -51,6 +51,11 @@ class Mlp3Desc(C.Structure):
 MLP3_GROUP_MAX = 8
 
 
+class GCopyDesc(C.Structure):
+    """hhrl_gcopy_desc of include/hhrl_hip.h."""
+    _fields_ = [("inp", _P), ("ldi", _L), ("out", _P), ("ldo", _I), ("C", _I), ("gather", _I)]
+
+
 class LinearFwdDesc(C.Structure):
     """hhrl_linear_fwd_desc of include/hhrl_hip.h."""
     _fields_ = [("x", _P), ("ldx", _I), ("w", _P), ("b", _P), ("y", _P), ("ldy", _I),
@@ -81,6 +86,7 @@ SIGNATURES = {
     "hhrl_copy2d": (_I, [_P, _I, _P, _I, _I, _I, _P]),
     "hhrl_copy2d_group": (_I, [_P, _I, _I, _P]),
     "hhrl_gather_rows": (_I, [_P, _L, _I, _P, _P, _I, _I, _I, _P]),
+    "hhrl_gather_copy_group": (_I, [_P, _I, _I, _P, _I, _P]),
     "hhrl_fill": (_I, [_P, _L, _F, _P]),
     "hhrl_randn_fill": (_I, [_P, _L, C.c_ulonglong, C.c_ulonglong, _P]),
     "hhrl_vae_reparam": (_I, [_P, _P, _P, _I, _I, _P]),

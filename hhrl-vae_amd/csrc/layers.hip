@@ -170,6 +170,27 @@ __global__ void copy2d_group_kernel(CopyGroup grp, int M) {
   g.out[r * g.ldo + c] = g.in[r * g.ldi + c];
 }
 
+// copy2d_group_kernel whose copies may read row idx[r] of their source instead of row r: the minibatch gather out of
+// a device-resident replay buffer and every copy of replay columns into a network input as ONE launch (the copies then
+// read the replay buffer directly instead of waiting for the gathered rows).
+struct GCopyInst { const float* in; float* out; long ldi; int ldo, C, gather; };
+struct GCopyGroup { GCopyInst in[HHRL_COPY_GROUP_MAX]; };
+__global__ void gather_copy_group_kernel(GCopyGroup grp, int M, const int* __restrict__ idx, int n_in) {
+  const GCopyInst& g = grp.in[blockIdx.y];
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g.in == nullptr) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (4 * e + u < g.C) g.out[4 * e + u] = 0.f;
+    return;
+  }
+  if (e >= (long)M * g.C) return;
+  const int c = e % g.C;
+  const long r = e / g.C;
+  const long src = g.gather ? (long)min(max(idx[r], 0), n_in - 1) : r;      // an index outside the buffer cannot leave it
+  g.out[r * g.ldo + c] = g.in[src * g.ldi + c];
+}
+
 __global__ void fill_kernel(float* p, long n, float v) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < n) p[idx] = v;
@@ -455,6 +476,34 @@ int hhrl_copy2d_group(const hhrl_copy_desc* d, int n, int M, void* stream) {
   ProfScope ps("copy2d_group_kernel", as_stream(stream), 0.0, bytes);
   hipLaunchKernelGGL(copy2d_group_kernel, dim3(ceil_div(threads, 256), n), dim3(256), 0, as_stream(stream), g, M);
   return launch_status("copy2d_group_kernel");
+}
+
+int hhrl_gather_copy_group(const hhrl_gcopy_desc* d, int n, int M, const int* idx, int n_in, void* stream) {
+  HHRL_REQUIRE(d && n >= 1 && n <= HHRL_COPY_GROUP_MAX, "gather_copy_group: %d blocks (1..%d supported)", n, HHRL_COPY_GROUP_MAX);
+  HHRL_REQUIRE(M > 0, "gather_copy_group: M=%d", M);
+  GCopyGroup g;
+  long threads = 0;
+  double bytes = 0.0;
+  for (int i = 0; i < n; ++i) {
+    HHRL_REQUIRE(d[i].out, "gather_copy_group: block %d: null pointer", i);
+    HHRL_REQUIRE(d[i].C > 0, "gather_copy_group: block %d: C=%d", i, d[i].C);
+    long need;
+    if (d[i].in) {
+      HHRL_REQUIRE(d[i].ldi >= d[i].C && d[i].ldo >= d[i].C, "gather_copy_group: block %d: bad shape C=%d ldi=%ld ldo=%d", i, d[i].C,
+                   d[i].ldi, d[i].ldo);
+      HHRL_REQUIRE(!d[i].gather || (idx && n_in > 0), "gather_copy_group: block %d gathers, but there are no row numbers", i);
+      need = (long)M * d[i].C;
+      bytes += 8.0 * M * d[i].C;
+    } else {
+      need = ((long)d[i].C + 3) / 4;
+      bytes += 4.0 * d[i].C;
+    }
+    g.in[i] = GCopyInst{d[i].in, d[i].out, d[i].ldi, d[i].ldo, d[i].C, d[i].gather};
+    threads = need > threads ? need : threads;
+  }
+  ProfScope ps("gather_copy_group_kernel", as_stream(stream), 0.0, bytes);
+  hipLaunchKernelGGL(gather_copy_group_kernel, dim3(ceil_div(threads, 256), n), dim3(256), 0, as_stream(stream), g, M, idx, n_in);
+  return launch_status("gather_copy_group_kernel");
 }
 
 int hhrl_fill(float* p, long n, float value, void* stream) {

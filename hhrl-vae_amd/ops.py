@@ -217,23 +217,42 @@ def copy2d(inp: int, ldi: int, out: int, ldo: int, M: int, Cc: int) -> None:
 class CopyQueue:
     """Collects [M, C] block copies that do not depend on each other and issues them as one launch."""
 
-    def __init__(self, M: int):
+    def __init__(self, M: int, gather=None):
+        """gather = (rows_ptr, row_width, table_ptr, n_table_rows, idx_ptr): the [M, row_width] block at rows_ptr is
+        itself row idx[r] of a device-resident table.  The queue then fills that block in the same launch, and copies
+        that read a column range of it read the table directly (they do not wait for the gathered rows)."""
         self.M = M
         self.items = []
+        self.gather = gather
+        if gather is not None:
+            rows, W, table, n_in, idx = gather
+            self.items.append((table, W, rows, W, W, 1))
 
     def add(self, inp: int, ldi: int, out: int, ldo: int, Cc: int) -> None:
-        self.items.append((inp, ldi, out, ldo, Cc))
+        if self.gather is not None:
+            rows, W, table, n_in, idx = self.gather
+            off = inp - rows
+            if ldi == W and 0 <= off and off + 4 * Cc <= 4 * W:      # a column range of the gathered rows
+                self.items.append((table + off, W, out, ldo, Cc, 1))
+                return
+        self.items.append((inp, ldi, out, ldo, Cc, 0))
 
     def add_zero(self, out: int, n: int) -> None:
         """n floats at `out` set to zero in the same launch (a gradient buffer's zero_grad)."""
-        self.items.append((None, 0, out, 0, n))
+        self.items.append((None, 0, out, 0, n, 0))
 
     def flush(self) -> None:
         lib = _lib.load()
         for i in range(0, len(self.items), _lib.COPY_GROUP_MAX):
             part = self.items[i:i + _lib.COPY_GROUP_MAX]
+            if self.gather is not None:
+                arr = (_lib.GCopyDesc * len(part))()
+                for d, (inp, ldi, out, ldo, Cc, ga) in zip(arr, part):
+                    d.inp, d.ldi, d.out, d.ldo, d.C, d.gather = inp, ldi, out, ldo, Cc, ga
+                check(lib.hhrl_gather_copy_group(arr, len(part), self.M, self.gather[4], self.gather[3], _lib.stream_ptr()))
+                continue
             arr = (_lib.CopyDesc * len(part))()
-            for d, (inp, ldi, out, ldo, Cc) in zip(arr, part):
+            for d, (inp, ldi, out, ldo, Cc, _) in zip(arr, part):
                 d.inp, d.ldi, d.out, d.ldo, d.C = inp, ldi, out, ldo, Cc
             check(lib.hhrl_copy2d_group(arr, len(part), self.M, _lib.stream_ptr()))
         self.items = []

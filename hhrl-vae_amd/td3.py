@@ -797,8 +797,7 @@ class TD3Learner:
         fam, lib, sp = self.fam, self._lib, _lib.stream_ptr()
         W = fam.row_width
         rows, noise, pi, y = st.rows, st.noise, st.pi, st.y
-        if getattr(st, "gather", False):
-            check(lib.hhrl_gather_rows(P(self._dev_mem), W, self.memory_capacity, st.idx.data_ptr(), P(rows), W, B, W, sp))
+        gather = bool(getattr(st, "gather", False))
         inv_n = 1.0 / float(getattr(st, "global_batch", B * self.world_size))
         R = lambda col: P(rows, col)
         goal = R(self.col_goal) if fam.goal_dim else None
@@ -817,9 +816,9 @@ class TD3Learner:
         items = [a.lstm_item(B, next_obs[k][0], W, True) for k, a in enumerate(self.actor_targets) if a.lstm is not None]
         items += [ct.feature_item(k, B, next_obs[k][0], W, True) for k in range(n_str)]
         items += [c.feature_item(k, B, obs[k][0], W) for k in range(n_str)]
-        self._lstm_forward(items, B)
-        # every piece of a network input that is a plain column range of the sampled rows: one launch
-        cq = ops.CopyQueue(B)
+        # every piece of a network input that is a plain column range of the sampled rows: one launch -- with a
+        # device-resident replay buffer the launch that gathers the rows themselves (the copies read the buffer)
+        cq = ops.CopyQueue(B, (P(rows), W, P(self._dev_mem), self.memory_capacity, st.idx.data_ptr()) if gather else None)
         for k, a in enumerate(self.actor_targets):
             a.stage_inputs(cq, B, next_obs[k][0], W, next_goal, W)
         ct.stage_inputs(cq, B, next_obs, next_goal, W)
@@ -841,6 +840,7 @@ class TD3Learner:
             for a in self.actors:
                 cq.add_zero(a.opt.g.base_ptr, a.opt.g.data.numel())
         cq.flush()
+        self._lstm_forward(items, B)
 
         # target policies: layer k of every actor in one launch, then the smoothing noise
         for k, a in enumerate(self.actor_targets):

@@ -114,6 +114,12 @@ int hhrl_copy2d_group(const hhrl_copy_desc* blocks, int n, int M, void* stream);
  * (in: [n_in][ldi] fp32, idx: M int32 row numbers; numbers outside [0, n_in) are clamped). */
 int hhrl_gather_rows(const float* in, long ldi, int n_in, const int* idx, float* out, int ldo, int M, int C,
                      void* stream);
+/* hhrl_copy2d_group whose blocks may gather: a block with gather != 0 reads row idx[r] of its source (in: a column of
+ * the replay buffer, ldi: the buffer's row width) instead of row r; row numbers outside [0, n_in) are clamped.  The
+ * minibatch gather of hhrl_gather_rows, every torch.cat piece that is a column range of the sampled rows and the
+ * zero_grad fills of an update as ONE launch (algorithm.py:287, 483, 772, 1320 and the lines cited above). */
+typedef struct { const float* in; long ldi; float* out; int ldo; int C; int gather; } hhrl_gcopy_desc;
+int hhrl_gather_copy_group(const hhrl_gcopy_desc* blocks, int n, int M, const int* idx, int n_in, void* stream);
 /* p[i] = value */
 int hhrl_fill(float* p, long n, float value, void* stream);
 /* out[i] = element (offset + i) of the standard-normal stream of `seed`, i < n: the draws of `torch.randn_like`

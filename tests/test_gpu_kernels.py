@@ -541,6 +541,39 @@ def test_copy2d_group(env):
     assert lib.hhrl_copy2d_group(arr, 0, M, None) != 0
 
 
+def test_gather_copy_group(env):
+    """hhrl_gather_copy_group: gathering blocks read row idx[r] of the table (row numbers outside it clamped), plain
+    blocks row r, zero fills ride along; everything outside the written ranges stays as it was."""
+    lib, L, dev = env
+    M, W, n_in = 37, 29, 100
+    g = torch.Generator().manual_seed(5)
+    table = torch.randn(n_in, W, generator=g).to(dev)
+    plain = torch.randn(M, 11, generator=g).to(dev)
+    idx = torch.randint(0, n_in, (M,), generator=g, dtype=torch.int32)
+    idx[3], idx[7] = -5, n_in + 9
+    idx_d = idx.to(dev)
+    rows = torch.full((M, W), 9.0, device=dev)
+    a = torch.full((M, 20), 9.0, device=dev)
+    b = torch.full((M, 8), 9.0, device=dev)
+    z = torch.full((70,), 9.0, device=dev)
+    d = (L.GCopyDesc * 5)()
+    specs = [(table.data_ptr(), W, rows.data_ptr(), W, W, 1),                      # the rows themselves
+             (table.data_ptr() + 4 * 5, W, a.data_ptr() + 4 * 2, 20, 13, 1),        # columns 5..17 of the gathered rows
+             (table.data_ptr() + 4 * 28, W, b.data_ptr(), 8, 1, 1),                 # the last column
+             (plain.data_ptr() + 4 * 1, 11, b.data_ptr() + 4 * 3, 8, 4, 0),         # a plain copy
+             (None, 0, z.data_ptr() + 4 * 3, 0, 61, 0)]                             # a zero fill
+    for k, (inp, ldi, out, ldo, Cc, ga) in enumerate(specs):
+        d[k].inp, d[k].ldi, d[k].out, d[k].ldo, d[k].C, d[k].gather = inp, ldi, out, ldo, Cc, ga
+    L.check(lib.hhrl_gather_copy_group(d, 5, M, idx_d.data_ptr(), n_in, L.stream_ptr()))
+    want = table[idx_d.long().clamp(0, n_in - 1)]
+    assert torch.equal(rows, want)
+    assert torch.equal(a[:, 2:15], want[:, 5:18]) and torch.all(a[:, :2] == 9.0) and torch.all(a[:, 15:] == 9.0)
+    assert torch.equal(b[:, 0], want[:, 28]) and torch.equal(b[:, 3:7], plain[:, 1:5])
+    assert torch.all(b[:, 1:3] == 9.0) and torch.all(b[:, 7] == 9.0)
+    assert torch.all(z[3:64] == 0.0) and torch.all(z[:3] == 9.0) and torch.all(z[64:] == 9.0)
+    assert lib.hhrl_gather_copy_group(d, 5, M, None, n_in, L.stream_ptr()) != 0 and b"row numbers" in lib.hhrl_last_error()
+
+
 @pytest.mark.parametrize("M,K0,N3,act3", [(64, 17, 1, 2), (64, 18, 1, 0), (37, 64, 32, 3), (4096, 11, 4, 2), (1, 1, 1, 0),
                                             (1000, 33, 17, 3), (20000, 18, 1, 0)])
 def test_mlp3_fused_matches_torch(env, M, K0, N3, act3):
