@@ -67,7 +67,7 @@ def td3_inputs(case: str, fx: Dict[str, np.ndarray], shapes_by_net):
     return init, rows
 
 
-def adam_path_close(name, got_p, want_p, grads_by_step, lrs, g_floor=2e-6, rtol=1e-4, max_saturated=None):
+def adam_path_close(name, got_p, want_p, grads_by_step, lrs, g_floor=2e-6, rtol=1e-4, max_saturated=None, zero_is_exact=False):
     """Parameters after a sequence of Adam steps, element by element.
 
     Adam normalises the gradient: a step moves a weight by about lr * g/|g| while the moments are young, so a
@@ -82,13 +82,18 @@ def adam_path_close(name, got_p, want_p, grads_by_step, lrs, g_floor=2e-6, rtol=
     An element whose gradient sits in the noise at most steps ends up with an allowance near 2.2 * sum(lr), the
     furthest Adam can move a weight at all: it is then effectively unchecked.  The share of such elements
     (allowance beyond half of that ceiling) over all tensors is returned, and with max_saturated it is asserted
-    to stay below that share, so that the check cannot quietly turn into one that passes anything."""
+    to stay below that share, so that the check cannot quietly turn into one that passes anything.
+
+    zero_is_exact: a reference gradient that is exactly 0.0 (a weight behind a ReLU that is off for the whole batch, a
+    padded column) is taken as structurally zero -- the other implementation must not move that weight at all -- instead of
+    as a gradient of unknown sign."""
     acc = {k: 0.0 for k in want_p}
     for grads, lr in zip(grads_by_step, lrs):
         for k in want_p:
             g = np.abs(np.asarray(grads[k], dtype=np.float64))
             dg = g_floor * max(float(g.max()) if g.size else 0.0, 1e-30)
-            acc[k] = acc[k] + lr * np.minimum(2.2, 6.0 * dg / (g + 1e-30))
+            step = lr * np.minimum(2.2, 6.0 * dg / (g + 1e-30))
+            acc[k] = acc[k] + (np.where(g == 0.0, 0.0, step) if zero_is_exact else step)
     ceiling = 2.2 * float(sum(lrs))
     n_sat = n_all = 0
     for k, w in want_p.items():

@@ -128,26 +128,28 @@ def test_four_intersections_stream_matches_oracle():
     # policy step), so the network's bar bounds it too.  What that bar still checks: an element whose gradient sits
     # below ~3 G_FLOOR of its tensor's largest at most steps is allowed nearly all of Adam's reach and is in effect
     # unchecked at the end (it is checked through everything it feeds: the actions and replay rows above, the losses
-    # and gradients of the kernel tests).  adam_path_close reports that share per network (measured: 31-42 % of the
-    # manager's elements over 14 / 7 steps, 44-59 % of the worker's over 224 / 112); MAX_SATURATED keeps it from
-    # growing unnoticed, e.g. through a larger G_FLOOR.
+    # and gradients of the kernel tests).  adam_path_close reports that share per network.  Elements whose reference
+    # gradient is exactly zero at a step (weights behind units that are off for the whole minibatch: a third to a half
+    # of these networks' elements) are held to NO movement at that step (zero_is_exact) instead of being counted as
+    # gradients of unknown sign; what remains saturated is 4-9 % of the manager's elements over 14 / 7 steps and
+    # 0.2-2 % of the worker's over 224 / 112, and MAX_SATURATED keeps it from growing unnoticed.
     G_FLOOR = 2e-4
-    MAX_SATURATED = 0.65
+    MAX_SATURATED = 0.15
     for net, onet, tag in ((mgr, o_mgr, "manager"), (wrk, o_wrk, "worker")):
         steps = onet.td3.total_it
         assert net.total_it == steps > 0 and len(onet.grad_log["critic"]) == steps
         sds, tgt = net.state_dicts(), net.target_state_dicts()
         np_ = lambda d: {k: v.detach().cpu().numpy() for k, v in d.items()}
         adam_path_close(tag + "/critic", np_(sds["critic"]), np_(onet.td3.critic), onet.grad_log["critic"],
-                        onet.lr_log["critic"], g_floor=G_FLOOR, max_saturated=MAX_SATURATED)
+                        onet.lr_log["critic"], g_floor=G_FLOOR, max_saturated=MAX_SATURATED, zero_is_exact=True)
         adam_path_close(tag + "/critic_target", np_(tgt["critic"]), np_(onet.td3.critic_target), onet.grad_log["critic"],
-                        onet.lr_log["critic"], g_floor=G_FLOOR)
+                        onet.lr_log["critic"], g_floor=G_FLOOR, max_saturated=MAX_SATURATED, zero_is_exact=True)
         for k, nme in enumerate(net.actor_names):
             assert len(onet.grad_log[nme]) == steps // 2
             adam_path_close(tag + "/" + nme, np_(sds[nme]), np_(onet.td3.actors[k]), onet.grad_log[nme], onet.lr_log[nme],
-                            g_floor=G_FLOOR, max_saturated=MAX_SATURATED)
+                            g_floor=G_FLOOR, max_saturated=MAX_SATURATED, zero_is_exact=True)
             adam_path_close(tag + "/" + nme + "_target", np_(tgt[nme]), np_(onet.td3.actor_targets[k]), onet.grad_log[nme],
-                            onet.lr_log[nme], g_floor=G_FLOOR)
+                            onet.lr_log[nme], g_floor=G_FLOOR, max_saturated=MAX_SATURATED, zero_is_exact=True)
 
 
 def test_four_intersections_batched_inference_same_values():

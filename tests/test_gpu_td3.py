@@ -155,11 +155,11 @@ def test_td3_benched_batch_sizes_vs_oracle(kind, batch):
             lrlog[names[i]].append(lr_a[i])
     np_ = lambda d: {k: v.detach().cpu().numpy() for k, v in d.items()}
     sds, tgt = net.state_dicts(), net.target_state_dicts()
-    adam_path_close("critic", np_(sds["critic"]), np_(oracle.critic), glog["critic"], lrlog["critic"], g_floor=1e-5)
-    adam_path_close("critic_target", np_(tgt["critic"]), np_(oracle.critic_target), glog["critic"], lrlog["critic"], g_floor=1e-5)
+    adam_path_close("critic", np_(sds["critic"]), np_(oracle.critic), glog["critic"], lrlog["critic"], g_floor=1e-5, zero_is_exact=True)
+    adam_path_close("critic_target", np_(tgt["critic"]), np_(oracle.critic_target), glog["critic"], lrlog["critic"], g_floor=1e-5, zero_is_exact=True)
     for i, n in enumerate(names):
-        adam_path_close(n, np_(sds[n]), np_(oracle.actors[i]), glog[n], lrlog[n], g_floor=2e-5)
-        adam_path_close(n + "_target", np_(tgt[n]), np_(oracle.actor_targets[i]), glog[n], lrlog[n], g_floor=2e-5)
+        adam_path_close(n, np_(sds[n]), np_(oracle.actors[i]), glog[n], lrlog[n], g_floor=2e-5, zero_is_exact=True)
+        adam_path_close(n + "_target", np_(tgt[n]), np_(oracle.actor_targets[i]), glog[n], lrlog[n], g_floor=2e-5, zero_is_exact=True)
 
 
 def test_td3_store_and_sample_surface():
