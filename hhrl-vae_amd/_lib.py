@@ -19,6 +19,9 @@ _L = C.c_long
 _F = C.c_float
 _D = C.c_double
 
+ABI_VERSION = 101            # HHRL_ABI_VERSION of include/hhrl_hip.h
+
+
 class LstmDesc(C.Structure):
     """hhrl_lstm_desc of include/hhrl_hip.h."""
     _fields_ = [("obs", _P), ("ldobs", _I), ("o", _I), ("params", _P), ("grads", _P), ("out", _P), ("ldo", _I),
@@ -137,6 +140,9 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    if lib.hhrl_version() != ABI_VERSION:
+        raise RuntimeError("%s was built for ABI version %d, these bindings are written for %d (the descriptor structs differ): "
+                           "rebuild it with `python hhrl-vae_amd/build.py`" % (path, lib.hhrl_version(), ABI_VERSION))
     _lib = lib
     return lib
 

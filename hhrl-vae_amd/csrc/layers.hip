@@ -253,7 +253,7 @@ using namespace hhrl;
 
 extern "C" {
 
-int hhrl_version(void) { return 100; }
+int hhrl_version(void) { return HHRL_ABI_VERSION; }
 const char* hhrl_last_error(void) { return err_buf(); }
 
 int hhrl_linear_forward(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int K,

@@ -34,6 +34,10 @@ extern "C" {
 #define HHRL_ACT_SIGMOID 3
 
 /* Library identification / diagnostics. */
+/* The ABI version this header describes; hhrl_version() returns the one the library was built with.  A binding checks
+ * that they agree before it passes descriptor structs (their layout is part of the ABI).
+ * 101: hhrl_lstm_desc gained `no_backward`; hhrl_gather_copy_group, hhrl_randn_fill, hhrl_vae_learn_steps added. */
+#define HHRL_ABI_VERSION 101
 int hhrl_version(void);
 const char* hhrl_last_error(void);
 

@@ -31,7 +31,9 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     assert not missing, "declared in hhrl_hip.h but not exported: %s" % missing
-    assert lib.hhrl_version() >= 100
+    header = open(os.path.join(ROOT, "include", "hhrl_hip.h")).read()
+    declared = int(re.search(r"#define\s+HHRL_ABI_VERSION\s+(\d+)", header).group(1))
+    assert lib.hhrl_version() == declared == _lib.ABI_VERSION
 
 
 def test_ctypes_table_matches_header():
