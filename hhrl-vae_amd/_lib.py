@@ -78,6 +78,7 @@ SIGNATURES = {
     "hhrl_last_error": (C.c_char_p, []),
     "hhrl_linear_forward": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "hhrl_linear_backward": (_I, [_P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "hhrl_linear_backward_row": (_I, [_P, _P, _I, _P, _F, _P, _I, _I, _I, _I, _I, _I, _P]),
     "hhrl_linear_forward_group": (_I, [_P, _I, _I, _P]),
     "hhrl_linear_backward_group": (_I, [_P, _I, _I, _P]),
     "hhrl_mlp3_supported": (_I, [_I, _I, _I, _I]),

@@ -153,6 +153,8 @@ struct GemmArgs {
   const float* smooth_eps;
   float* y2;
   long ldy2;
+  // The accumulated product is multiplied by alpha before bias, accumulation and activation (1 unless a caller sets it).
+  float alpha;
 };
 constexpr int kGemmGroupMax = 16;
 struct GemmGroup {

@@ -309,6 +309,7 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& g, int bx, int b
     if (gi >= g.M || gj >= g.N) continue;
     float v = (part(0)[row][col] + part(1)[row][col]) + (part(2)[row][col] + part(3)[row][col]);
     if (NW == 8) v += (part(4)[row][col] + part(5)[row][col]) + (part(6)[row][col] + part(7)[row][col]);
+    v *= g.alpha;
     float* c = g.C + (long)gi * g.ldc + gj;
     if (g.mode == 2) {
       unsafeAtomicAdd(c, v);
@@ -483,6 +484,7 @@ __device__ __forceinline__ void gemm_tiny_body(const GemmArgs& g, int bx, int by
     if (gi < g.M && gj < g.N) {
       float v = ((stage[0][0][row][col] + stage[1][0][row][col]) + (stage[2][0][row][col] + stage[3][0][row][col])) +
                 ((stage[4][0][row][col] + stage[5][0][row][col]) + (stage[6][0][row][col] + stage[7][0][row][col]));
+      v *= g.alpha;
       float* c = g.C + (long)gi * g.ldc + gj;
       if (g.mode == 2) {
         unsafeAtomicAdd(c, v);
@@ -533,7 +535,7 @@ static int small_waves() {
 GemmArgs gemm_args(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj, float* C, long ldc,
                    int M, int N, int K, const float* bias, int act, int mode) {
   return GemmArgs{A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, M, N, K, K, act, mode, a_sk == 1, b_sk == 1,
-                  nullptr, 0, 0, HHRL_ACT_NONE, nullptr, nullptr, nullptr, nullptr, 0};
+                  nullptr, 0, 0, HHRL_ACT_NONE, nullptr, nullptr, nullptr, nullptr, 0, 1.0f};
 }
 
 // Most 32 x 32 output tiles a product may have to be served by the small-product kernels (HHRL_GEMM_SMALL_MAX
@@ -641,7 +643,8 @@ static int gemm_one(GemmArgs g, hipStream_t st) {
     else hipLaunchKernelGGL(gemm_small_kernel<4>, grid, dim3(256), 0, st, g);
     return launch_status("gemm_small_kernel");
   }
-  HHRL_REQUIRE(!g.Y && !g.rowsum && !g.smooth_eps, "gemm: operand mask / row sums / smoothing are served by the small-product kernels only (M=%d N=%d)", M, N);
+  HHRL_REQUIRE(!g.Y && !g.rowsum && !g.smooth_eps && g.alpha == 1.0f,
+               "gemm: operand mask / row sums / smoothing / scaling are served by the small-product kernels only (M=%d N=%d)", M, N);
   const int TM = M > 1024 ? 2 : 1;
   const int TN = N > 64 ? 2 : 1;
   const int gx = ceil_div(N, 64 * TN), gy = ceil_div(M, 64 * TM);

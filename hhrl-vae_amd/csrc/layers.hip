@@ -310,6 +310,23 @@ int hhrl_linear_backward(const float* x, int ldx, const float* w, const float* y
   return gemm_group(g, m, st);
 }
 
+int hhrl_linear_backward_row(const float* w, const float* y, int ldy, const float* dy_row, float alpha, float* dx, int lddx,
+                             int dx_accumulate, int M, int K, int N, int act, void* stream) {
+  HHRL_REQUIRE(w && dy_row && dx, "linear_backward_row: null pointer");
+  HHRL_REQUIRE(M > 0 && K > 0 && N > 0, "linear_backward_row: non-positive size M=%d K=%d N=%d", M, K, N);
+  HHRL_REQUIRE(valid_act(act), "linear_backward_row: bad activation %d", act);
+  HHRL_REQUIRE(act == HHRL_ACT_NONE || (y && ldy >= N), "linear_backward_row: activation gradient needs y");
+  HHRL_REQUIRE(lddx >= K, "linear_backward_row: lddx=%d < K=%d", lddx, K);
+  // operand A(i, n) = dy_row[n] for every row i (row stride 0), masked by the activation gradient while it is loaded
+  GemmArgs g = gemm_args(dy_row, 0, 1, w, K, 1, dx, lddx, M, K, N, nullptr, HHRL_ACT_NONE, dx_accumulate ? 1 : 0);
+  HHRL_REQUIRE(gemm_is_small(g), "linear_backward_row: M=%d K=%d is beyond the small-product kernels", M, K);
+  if (act != HHRL_ACT_NONE) {
+    g.Y = y; g.y_si = ldy; g.y_sk = 1; g.y_act = act;
+  }
+  g.alpha = alpha;
+  return gemm_group(&g, 1, as_stream(stream));
+}
+
 int hhrl_linear_forward_group(const hhrl_linear_fwd_desc* d, int n, int M, void* stream) {
   HHRL_REQUIRE(d && n >= 1 && n <= kGemmGroupMax, "linear_forward_group: %d layers (1..%d supported)", n, kGemmGroupMax);
   HHRL_REQUIRE(M > 0, "linear_forward_group: M=%d", M);

@@ -52,6 +52,13 @@ class Lin:
                                              gw, gb, M, self.K, self.N, self.act, _lib.stream_ptr()))
 
 
+def linear_backward_row(lin: "Lin", y: int, ldy: int, dy_row: int, alpha: float, dx: int, lddx: int, M: int,
+                        dx_accumulate: int = 0) -> None:
+    """dx = alpha * ((dy_row for every sample) * act'(y)) W of layer `lin`: its input gradient when dL/dy is one row."""
+    check(_lib.load().hhrl_linear_backward_row(lin.w, y, ldy, dy_row, alpha, dx, lddx, dx_accumulate, M, lin.K, lin.N, lin.act,
+                                               _lib.stream_ptr()))
+
+
 def linear_forward_group(items, M: int) -> None:
     """items: [(Lin, x, ldx, y, ldy[, smooth_eps, y2, ldy2])]: independent layers on the same M rows, one launch."""
     n = len(items)

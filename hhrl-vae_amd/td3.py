@@ -298,7 +298,9 @@ class CriticNet:
         if not q1_only:
             self.mlp3[1].desc(d[start + 1], P(xu), self.D, P(w.q2), 1, P(w.b1), P(w.b2))
 
-    def heads(self, B: int, q1_only: bool = False, policy_input: bool = False) -> None:
+    def heads(self, B: int, q1_only: bool = False, policy_input: bool = False, hidden_only: bool = False) -> None:
+        """hidden_only (with q1_only, layer-by-layer heads): the two hidden layers without the output layer -- all the
+        policy step needs, whose gradient d(-mean Q1)/d(hidden 2) is a row of constants (backward(dq_const=...))."""
         w = self.work(B)
         h0, h1 = self.h
         if self.mlp3 is not None:
@@ -310,7 +312,8 @@ class CriticNet:
         if q1_only:
             self.l1.fwd(P(w.xu), self.D, P(w.a1), h0, B)
             self.l2.fwd(P(w.a1), h0, P(w.a2), h1, B)
-            self.l3.fwd(P(w.a2), h1, P(w.q1), 1, B)
+            if not hidden_only:
+                self.l3.fwd(P(w.a2), h1, P(w.q1), 1, B)
             return
         # the two heads are independent: layer k of both in one launch
         for level in (1, 2, 3):
@@ -359,6 +362,12 @@ class CriticNet:
             return
         d_q1 = P(w.d_q1)
         assert not policy_input, "the policy step's own input buffer is used with the fused three-layer heads only"
+        if dq_const is not None and not both_heads and not param_grads and self.l3.N == 1:
+            # dL/dQ1 is the same constant for every row, so dL/d(hidden 2) is dq_const times the output layer's weight row
+            # for every sample: the output layer takes no launch, its row is the operand of the second layer's product
+            ops.linear_backward_row(self.l2, P(w.a2), h1, self.l3.w, dq_const, P(w.d_a1), h0, B)
+            self.l1.bwd(P(w.xu), self.D, P(w.a1), h0, P(w.d_a1), h0, dxu, self.D, B, param_grads=False)
+            return
         if dq_const is not None:
             # The constant gradient lives in a buffer of its own, one per constant (the divisor is the global batch,
             # which a caller may vary at one B): filled once, on the first -- eager -- run of a launch chain, so a
@@ -909,7 +918,7 @@ class TD3Learner:
             for n, i in enumerate(order):
                 a = self.actors[i]
                 if not c.q1_input_gradient(B, -inv_n, policy_input=ahead):                                     # d(-mean Q1)/d(s, a)
-                    c.heads(B, q1_only=True, policy_input=ahead)
+                    c.heads(B, q1_only=True, policy_input=ahead, hidden_only=True)
                     c.backward(B, both_heads=False, param_grads=False, dq_const=-inv_n, policy_input=ahead)
                 a.backward(B, P(xu_act, c.act_cols[i]), c.D, P(cw.d_xu, c.act_cols[i]), c.D, lstm=False)
                 if a.lstm is not None:

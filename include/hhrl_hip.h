@@ -66,6 +66,14 @@ int hhrl_linear_backward(const float* x, int ldx, const float* w,
                          float* dx, int lddx, int dx_accumulate,
                          float* dw, float* db, int M, int K, int N, int act,
                          void* stream);
+/* The input gradient of such a layer when dL/dy is the SAME row for every sample, scaled by alpha:
+ *   dx[i][k] (op)= alpha * sum_n dy_row[n] * act'(y[i][n]) * w[n][k].
+ * That is the case of the layer below a one-output layer whose own output gradient is a constant: for the actor loss
+ * -mean(Q1) (algorithm.py:317, 528, 821, 1157, 1355) dQ1/d(hidden 2) is the row of l3's weights for every sample and
+ * alpha = -1/batch, so the last layer's input gradient takes no launch of its own (nor, in that step, its forward value).
+ * No parameter gradients (the policy step does not update the critic). */
+int hhrl_linear_backward_row(const float* w, const float* y, int ldy, const float* dy_row, float alpha,
+                             float* dx, int lddx, int dx_accumulate, int M, int K, int N, int act, void* stream);
 
 /* Several independent dense layers on the same M rows in ONE launch per stage
  * (the twin Q heads l1/l4, l2/l5, l3/l6 of the critics, algorithm.py:206-221,

@@ -121,6 +121,28 @@ def test_linear_backward_partial_outputs(env, M, K, N, act):
                 assert not got.any(), "%s written although it was not asked for" % name
 
 
+@pytest.mark.parametrize("M,K,N,act", [(64, 512, 256, 1), (64, 400, 300, 1), (1024, 512, 256, 1), (37, 19, 7, 2), (5, 3, 1, 0)])
+def test_linear_backward_row(env, M, K, N, act):
+    """hhrl_linear_backward_row: the input gradient of a layer whose output gradient is one row for every sample,
+    against autograd of alpha * sum_i <act(x_i W^T + b), row>; written or accumulated, inside a wider buffer."""
+    lib, L, dev = env
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).requires_grad_(True)
+    w, b, row = torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g), torch.randn(N, generator=g)
+    alpha = -1.0 / M
+    y = _act(F.linear(x, w, b), act)
+    (alpha * (y * row).sum()).backward()
+    d = lambda t: t.detach().to(dev).contiguous()
+    yd, wd, rowd = d(y), d(w), d(row)
+    dx = torch.full((M, K + 3), 3.0, device=dev)
+    st = L.stream_ptr()
+    L.check(lib.hhrl_linear_backward_row(wd.data_ptr(), yd.data_ptr(), N, rowd.data_ptr(), alpha, dx.data_ptr(), K + 3, 0, M, K, N, act, st))
+    scaled_close("dx", dx[:, :K].cpu().numpy(), x.grad.numpy(), atol_rel=5e-6)
+    assert torch.all(dx[:, K:] == 3.0)
+    L.check(lib.hhrl_linear_backward_row(wd.data_ptr(), yd.data_ptr(), N, rowd.data_ptr(), alpha, dx.data_ptr(), K + 3, 1, M, K, N, act, st))
+    scaled_close("dx2", dx[:, :K].cpu().numpy(), 2 * x.grad.numpy(), atol_rel=5e-6)
+
+
 def test_argument_errors(env):
     lib, L, dev = env
     t = torch.zeros(16, device=dev)
