@@ -79,6 +79,7 @@ SIGNATURES = {
     "hhrl_linear_forward": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "hhrl_linear_backward": (_I, [_P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P]),
     "hhrl_linear_backward_row": (_I, [_P, _P, _I, _P, _F, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "hhrl_linear_backward_cols": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "hhrl_linear_forward_group": (_I, [_P, _I, _I, _P]),
     "hhrl_linear_backward_group": (_I, [_P, _I, _I, _P]),
     "hhrl_mlp3_supported": (_I, [_I, _I, _I, _I]),

@@ -327,6 +327,22 @@ int hhrl_linear_backward_row(const float* w, const float* y, int ldy, const floa
   return gemm_group(&g, 1, as_stream(stream));
 }
 
+int hhrl_linear_backward_cols(const float* w, int K, const float* y, int ldy, const float* dy, int lddy, float* dx, int lddx,
+                              int dx_accumulate, int c0, int nc, int M, int N, int act, void* stream) {
+  HHRL_REQUIRE(w && dy && dx, "linear_backward_cols: null pointer");
+  HHRL_REQUIRE(M > 0 && K > 0 && N > 0, "linear_backward_cols: non-positive size M=%d K=%d N=%d", M, K, N);
+  HHRL_REQUIRE(c0 >= 0 && nc > 0 && c0 + nc <= K, "linear_backward_cols: columns [%d, %d) of %d", c0, c0 + nc, K);
+  HHRL_REQUIRE(valid_act(act), "linear_backward_cols: bad activation %d", act);
+  HHRL_REQUIRE(act == HHRL_ACT_NONE || (y && ldy >= N), "linear_backward_cols: activation gradient needs y");
+  HHRL_REQUIRE(lddy >= N && lddx >= K, "linear_backward_cols: lddy=%d < N=%d or lddx=%d < K=%d", lddy, N, lddx, K);
+  GemmArgs g = gemm_args(dy, lddy, 1, w + c0, K, 1, dx + c0, lddx, M, nc, N, nullptr, HHRL_ACT_NONE, dx_accumulate ? 1 : 0);
+  HHRL_REQUIRE(gemm_is_small(g), "linear_backward_cols: M=%d is beyond the small-product kernels", M);
+  if (act != HHRL_ACT_NONE) {
+    g.Y = y; g.y_si = ldy; g.y_sk = 1; g.y_act = act;
+  }
+  return gemm_group(&g, 1, as_stream(stream));
+}
+
 int hhrl_linear_forward_group(const hhrl_linear_fwd_desc* d, int n, int M, void* stream) {
   HHRL_REQUIRE(d && n >= 1 && n <= kGemmGroupMax, "linear_forward_group: %d layers (1..%d supported)", n, kGemmGroupMax);
   HHRL_REQUIRE(M > 0, "linear_forward_group: M=%d", M);

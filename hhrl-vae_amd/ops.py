@@ -59,6 +59,13 @@ def linear_backward_row(lin: "Lin", y: int, ldy: int, dy_row: int, alpha: float,
                                                _lib.stream_ptr()))
 
 
+def linear_backward_cols(lin: "Lin", y: int, ldy: int, dy: int, lddy: int, dx: int, lddx: int, c0: int, nc: int, M: int,
+                         dx_accumulate: int = 0) -> None:
+    """Columns [c0, c0 + nc) of layer `lin`'s input gradient (the others are left alone)."""
+    check(_lib.load().hhrl_linear_backward_cols(lin.w, lin.K, y, ldy, dy, lddy, dx, lddx, dx_accumulate, c0, nc, M, lin.N, lin.act,
+                                                _lib.stream_ptr()))
+
+
 def linear_forward_group(items, M: int) -> None:
     """items: [(Lin, x, ldx, y, ldy[, smooth_eps, y2, ldy2])]: independent layers on the same M rows, one launch."""
     n = len(items)

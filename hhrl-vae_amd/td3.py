@@ -339,11 +339,13 @@ class CriticNet:
             self.lstms[k].bwd(P(w.d_xu, self.feat_cols[k]), self.D, w.lstm_ws[k], B)
 
     def backward(self, B: int, both_heads: bool, param_grads: bool, lstms: bool = True,
-                 dq_const: Optional[float] = None, policy_input: bool = False) -> None:
+                 dq_const: Optional[float] = None, policy_input: bool = False, dx_cols: Optional[Tuple[int, int]] = None) -> None:
         """Back-propagates w.d_q1 (and w.d_q2) to w.d_xu; with param_grads also
         into the critic's gradient buffer (its LSTMs too unless lstms=False:
         the caller then runs lstm_backward per stream).  dq_const: dL/dQ1 is
-        this constant for every row (the gradient of -mean Q1) instead of w.d_q1."""
+        this constant for every row (the gradient of -mean Q1) instead of w.d_q1.  dx_cols = (first column, count):
+        only those columns of w.d_xu are wanted (one actor's action columns on a policy step); honoured where it
+        saves work, else the whole of w.d_xu is written."""
         w = self.work(B)
         h0, h1 = self.h
         has_lstm = any(l is not None for l in self.lstms)
@@ -366,7 +368,10 @@ class CriticNet:
             # dL/dQ1 is the same constant for every row, so dL/d(hidden 2) is dq_const times the output layer's weight row
             # for every sample: the output layer takes no launch, its row is the operand of the second layer's product
             ops.linear_backward_row(self.l2, P(w.a2), h1, self.l3.w, dq_const, P(w.d_a1), h0, B)
-            self.l1.bwd(P(w.xu), self.D, P(w.a1), h0, P(w.d_a1), h0, dxu, self.D, B, param_grads=False)
+            if dx_cols is not None:
+                ops.linear_backward_cols(self.l1, P(w.a1), h0, P(w.d_a1), h0, dxu, self.D, dx_cols[0], dx_cols[1], B)
+            else:
+                self.l1.bwd(P(w.xu), self.D, P(w.a1), h0, P(w.d_a1), h0, dxu, self.D, B, param_grads=False)
             return
         if dq_const is not None:
             # The constant gradient lives in a buffer of its own, one per constant (the divisor is the global batch,
@@ -919,7 +924,8 @@ class TD3Learner:
                 a = self.actors[i]
                 if not c.q1_input_gradient(B, -inv_n, policy_input=ahead):                                     # d(-mean Q1)/d(s, a)
                     c.heads(B, q1_only=True, policy_input=ahead, hidden_only=True)
-                    c.backward(B, both_heads=False, param_grads=False, dq_const=-inv_n, policy_input=ahead)
+                    c.backward(B, both_heads=False, param_grads=False, dq_const=-inv_n, policy_input=ahead,
+                               dx_cols=(c.act_cols[i], fam.a_dims[i]))
                 a.backward(B, P(xu_act, c.act_cols[i]), c.D, P(cw.d_xu, c.act_cols[i]), c.D, lstm=False)
                 if a.lstm is not None:
                     self._lstm_backward([a.lstm_bwd_item(B)], B)

@@ -74,6 +74,12 @@ int hhrl_linear_backward(const float* x, int ldx, const float* w,
  * No parameter gradients (the policy step does not update the critic). */
 int hhrl_linear_backward_row(const float* w, const float* y, int ldy, const float* dy_row, float alpha,
                              float* dx, int lddx, int dx_accumulate, int M, int K, int N, int act, void* stream);
+/* Columns [c0, c0 + nc) of a layer's input gradient only:
+ *   dx[i][c0 + c] (op)= sum_n dy[i][n] * act'(y[i][n]) * w[n][c0 + c]      (w: [N, K] as in hhrl_linear_forward).
+ * The actor loss is differentiated with respect to ONE actor's action columns of the critic's input
+ * (algorithm.py:820-823: only optimizer i steps), not with respect to the states and the other actions beside them. */
+int hhrl_linear_backward_cols(const float* w, int K, const float* y, int ldy, const float* dy, int lddy,
+                              float* dx, int lddx, int dx_accumulate, int c0, int nc, int M, int N, int act, void* stream);
 
 /* Several independent dense layers on the same M rows in ONE launch per stage
  * (the twin Q heads l1/l4, l2/l5, l3/l6 of the critics, algorithm.py:206-221,

@@ -143,6 +143,31 @@ def test_linear_backward_row(env, M, K, N, act):
     scaled_close("dx2", dx[:, :K].cpu().numpy(), 2 * x.grad.numpy(), atol_rel=5e-6)
 
 
+@pytest.mark.parametrize("M,K,N,act,c0,nc", [(64, 393, 512, 1, 384, 4), (1024, 393, 512, 1, 389, 4), (33, 20, 9, 2, 0, 1), (7, 5, 3, 0, 2, 3)])
+def test_linear_backward_cols(env, M, K, N, act, c0, nc):
+    """hhrl_linear_backward_cols: the named columns of the input gradient equal those of hhrl_linear_backward's, the
+    others are not touched."""
+    lib, L, dev = env
+    g = torch.Generator().manual_seed(M + K + N + c0)
+    t = lambda *s: torch.randn(*s, generator=g).to(dev)
+    w, y, dy = t(N, K) / K ** 0.5, t(M, N), t(M, N)
+    if act == 1:
+        y = y.clamp_min(0.0)
+    elif act == 2:
+        y = torch.tanh(y)
+    st = L.stream_ptr()
+    full = torch.zeros(M, K, device=dev)
+    L.check(lib.hhrl_linear_backward(None, 0, w.data_ptr(), y.data_ptr(), N, dy.clone().data_ptr(), N, full.data_ptr(), K, 0, None, None,
+                                     M, K, N, act, st))
+    part = torch.full((M, K), 5.0, device=dev)
+    L.check(lib.hhrl_linear_backward_cols(w.data_ptr(), K, y.data_ptr(), N, dy.data_ptr(), N, part.data_ptr(), K, 0, c0, nc, M, N, act, st))
+    scaled_close("cols", part[:, c0:c0 + nc].cpu().numpy(), full[:, c0:c0 + nc].cpu().numpy(), atol_rel=5e-6)
+    mask = torch.ones(K, dtype=torch.bool)
+    mask[c0:c0 + nc] = False
+    assert torch.all(part[:, mask] == 5.0)
+    assert lib.hhrl_linear_backward_cols(w.data_ptr(), K, y.data_ptr(), N, dy.data_ptr(), N, part.data_ptr(), K, 0, K - 1, 2, M, N, act, st) != 0
+
+
 def test_argument_errors(env):
     lib, L, dev = env
     t = torch.zeros(16, device=dev)
