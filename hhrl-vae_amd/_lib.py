@@ -153,6 +153,29 @@ class HipError(RuntimeError):
     pass
 
 
+_hip_rt = None
+ZERO_COPY_MAX_FLOATS = 1 << 16
+
+
+def zero_copy_ok(pinned) -> bool:
+    """True when kernels may read and write this pinned host tensor in place, at its host address: the HIP runtime
+    reports a device address for it and that address is the host one (unified addressing; torch's pinned memory is
+    mapped).  The per-call inference paths then hand their pinned blocks straight to the kernels instead of staging
+    them through device buffers (one launch instead of copy + launch + copy).  HHRL_ZERO_COPY=0 turns it off; blocks
+    beyond ZERO_COPY_MAX_FLOATS are staged (a DMA copy moves large blocks faster than a kernel's own reads)."""
+    global _hip_rt
+    if os.environ.get("HHRL_ZERO_COPY") == "0" or pinned.numel() > ZERO_COPY_MAX_FLOATS or not pinned.is_pinned():
+        return False
+    try:
+        if _hip_rt is None:
+            _hip_rt = C.CDLL("libamdhip64.so")
+        dptr = C.c_void_p()
+        rc = _hip_rt.hipHostGetDevicePointer(C.byref(dptr), C.c_void_p(pinned.data_ptr()), 0)
+    except OSError:
+        return False
+    return rc == 0 and dptr.value == pinned.data_ptr()
+
+
 def check(rc: int) -> None:
     if rc != 0:
         msg = load().hhrl_last_error()

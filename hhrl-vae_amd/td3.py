@@ -1002,18 +1002,22 @@ class TD3Learner:
             if len(self._policy_io) > 32:
                 self._policy_io.clear()
             wid = s.width + gd
-            io = self._policy_io[key] = {"h_in": torch.zeros(n, wid, dtype=torch.float32).pin_memory(),
-                                         "d_in": ops.dev_empty(n, wid, device=self.device),
-                                         "d_out": ops.dev_empty(n, a, device=self.device),
-                                         "h_out": torch.zeros(n, a, dtype=torch.float32).pin_memory(),
+            h_in = torch.zeros(n, wid, dtype=torch.float32).pin_memory()
+            h_out = torch.zeros(n, a, dtype=torch.float32).pin_memory()
+            # small blocks are read and written by the kernels in place (no staging copies: one launch or replay per call)
+            zc = _lib.zero_copy_ok(h_in) and _lib.zero_copy_ok(h_out)
+            io = self._policy_io[key] = {"h_in": h_in, "h_out": h_out, "zc": zc,
+                                         "d_in": h_in if zc else ops.dev_empty(n, wid, device=self.device),
+                                         "d_out": h_out if zc else ops.dev_empty(n, a, device=self.device),
                                          "calls": 0, "graph": None}
-        h_in, d_in, d_out, h_out = io["h_in"], io["d_in"], io["d_out"], io["h_out"]
+        h_in, d_in, d_out, h_out, zc = io["h_in"], io["d_in"], io["d_out"], io["h_out"], io["zc"]
         wid = s.width + gd
         hv = h_in.numpy()
         hv[:, :s.width] = o
         if gd:
             hv[:, s.width:] = np.asarray(goal, dtype=np.float32).reshape(n, gd)
-        d_in.copy_(h_in, non_blocking=True)
+        if not zc:
+            d_in.copy_(h_in, non_blocking=True)
         run = lambda: self.actors[k].forward(n, P(d_in), wid, P(d_in, s.width) if gd else None, wid, P(d_out), a, no_backward=True)
         if io["graph"] is not None:
             io["graph"].replay()
@@ -1027,7 +1031,8 @@ class TD3Learner:
         else:
             io["calls"] += 1
             run()
-        h_out.copy_(d_out, non_blocking=True)
+        if not zc:
+            h_out.copy_(d_out, non_blocking=True)
         _lib.current_stream().synchronize()        # the pinned blocks are free again afterwards
         return h_out.numpy().copy()
 

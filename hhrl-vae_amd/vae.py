@@ -73,34 +73,40 @@ class _Work:
 
 
 class _InferIO:
-    """One pinned host block and one device block each way for the inference calls: a call writes all of
-    its inputs into the host block, uploads them with ONE transfer, launches, downloads the result with
-    ONE transfer and waits for the stream.  Blocks grow by doubling; a call owns them until it returns
+    """One pinned host block each way for the inference calls: a call writes all of its inputs into the host
+    block, launches, and waits for the stream.  Small blocks (every per-lane, per-intersection call of the agents)
+    are read and written by the kernels in place (`_lib.zero_copy_ok`): one launch per call; larger ones are staged
+    through device blocks with ONE transfer each way.  Blocks grow by doubling; a call owns them until it returns
     (the class surface is used from one thread, like the reference's)."""
 
     def __init__(self, dev):
         self.dev = dev
         self.n_in = self.n_out = 0
         self.h_in = self.d_in = self.h_out = self.d_out = None
+        self.zc_in = self.zc_out = False
 
     def reserve(self, n_in: int, n_out: int) -> None:
         if n_in > self.n_in:
             self.n_in = max(1024, 2 * self.n_in, n_in)
             self.h_in = torch.zeros(self.n_in, dtype=torch.float32).pin_memory()
-            self.d_in = ops.dev_empty(self.n_in, device=self.dev)
+            self.zc_in = _lib.zero_copy_ok(self.h_in)
+            self.d_in = self.h_in if self.zc_in else ops.dev_empty(self.n_in, device=self.dev)
             self.h_in_np = self.h_in.numpy()
             self.h_in_i32 = self.h_in_np.view(np.int32)
         if n_out > self.n_out:
             self.n_out = max(1024, 2 * self.n_out, n_out)
             self.h_out = torch.zeros(self.n_out, dtype=torch.float32).pin_memory()
-            self.d_out = ops.dev_empty(self.n_out, device=self.dev)
+            self.zc_out = _lib.zero_copy_ok(self.h_out)
+            self.d_out = self.h_out if self.zc_out else ops.dev_empty(self.n_out, device=self.dev)
             self.h_out_np = self.h_out.numpy()
 
     def upload(self, n: int) -> None:
-        self.d_in[:n].copy_(self.h_in[:n], non_blocking=True)
+        if not self.zc_in:
+            self.d_in[:n].copy_(self.h_in[:n], non_blocking=True)
 
     def download(self, n: int) -> np.ndarray:
-        self.h_out[:n].copy_(self.d_out[:n], non_blocking=True)
+        if not self.zc_out:
+            self.h_out[:n].copy_(self.d_out[:n], non_blocking=True)
         _lib.current_stream().synchronize()
         return self.h_out_np[:n].copy()
 
