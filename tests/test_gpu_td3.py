@@ -106,6 +106,32 @@ def test_td3_golden(case):
             scaled_close("policy", net.policy(fx["policy/o"], fx["policy/g"]), fx["policy/out"], atol_rel=5e-6)
 
 
+def test_policy_calls_staged_and_in_place_agree(monkeypatch):
+    """choose_* / policy with the calls' pinned blocks used in place by the kernels (default) and staged through
+    device buffers (HHRL_ZERO_COPY=0): the same bits, for a fused three-layer actor and for LSTM actors, whose
+    batch-1 evaluation turns into a graph replay on the third call."""
+    import hhrl_vae_amd.algorithm as A
+    rs = np.random.RandomState(6)
+    o_w, g_w = rs.uniform(0, 1, size=(5, 11)).astype(np.float32), rs.uniform(0, 1, size=(5, 6)).astype(np.float32)
+    o_t = [rs.uniform(0, 1, size=(130,)).astype(np.float32) for _ in range(4)]
+    o_g = rs.uniform(0, 1, size=(8, 250)).astype(np.float32)
+
+    def run():
+        w, t = A.WorkerTD3(gen.cav_cfg(cap=64), seed=3), A.HATD3Triple(gen.light_cfg(cap=64), seed=3)
+        out = [w.choose_action(o_w[0], g_w[0]), w.policy(o_w, g_w)]
+        out += [t.choose_time_action(o) for o in o_t]                       # eager, eager, capture + replay, replay
+        out += [t.choose_phase_action(o_t[0]), t.choose_goal_batch(o_g)]
+        return (w, t), out
+
+    (w, t), ra = run()
+    assert all(io["zc"] for net in (w, t) for io in net._policy_io.values())
+    monkeypatch.setenv("HHRL_ZERO_COPY", "0")
+    (w2, t2), rb = run()
+    assert not any(io["zc"] for net in (w2, t2) for io in net._policy_io.values())
+    for x, y in zip(ra, rb):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+
+
 @pytest.mark.parametrize("kind,batch", [("worker", 4096), ("triple", 1024)])
 def test_td3_benched_batch_sizes_vs_oracle(kind, batch):
     """The batch sizes bench.py times beside the reference's 64 -- WorkerTD3 at 4096 rows and HATD3Triple at

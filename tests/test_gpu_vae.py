@@ -134,6 +134,29 @@ def test_vae_train_all_converts_chunks_once(tmp_path):
             assert os.path.exists(os.path.join(str(tmp_path), "encoder_dim_%d%s" % (g, suf)))
 
 
+def test_inference_calls_staged_and_in_place_agree(monkeypatch):
+    """encode / encode_lanes / decode with the calls' pinned blocks read and written in place by the kernels (the
+    default for small blocks) and staged through device buffers (HHRL_ZERO_COPY=0): the same bits."""
+    from hhrl_vae_amd.algorithm import Encoder
+    rs = np.random.RandomState(4)
+    lanes = [rs.uniform(0, 1, size=(n, 2)).tolist() for n in (7, 1, 0, 30, 12)]
+    goal, eps = rs.standard_normal(8).astype(np.float32) * 0.3, rs.standard_normal((1, 4)).astype(np.float32)
+
+    def run():
+        e = Encoder(2, 4, seed=9)
+        assert e._io.n_in == 0
+        out = [e.encode(lanes[0]), e.encode_lanes(lanes), e.decode(goal, [0.4], eps=eps), e.encode(lanes[3])]
+        return e, out
+
+    a, ra = run()
+    assert a._io.zc_in and a._io.zc_out, "pinned blocks of this size are expected to be used in place"
+    monkeypatch.setenv("HHRL_ZERO_COPY", "0")
+    b, rb = run()
+    assert not b._io.zc_in and not b._io.zc_out
+    for x, y in zip(ra, rb):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+
+
 def test_vae_learn_many_equals_one_call_per_chunk():
     """Encoder.learn_many (hhrl_vae_learn_steps: a group of chunks per library call) takes exactly the steps of
     learn() chunk by chunk: ragged chunk shapes, more chunks than the loss ring holds, injected noise and the
