@@ -522,6 +522,12 @@ def main() -> None:
         return hdist.reduce_scalar(d, "max", group, device)
 
     progress("VAE step: %d lanes x %d cars, latent %d, %d rank(s)" % (B, N, g, world))
+    # The chip leaves its idle clocks only after some tens of milliseconds of work, far more than --warmup steps of
+    # 50 us each: a fixed, untimed stretch of steps first (the same count on every rank), so that the timed window
+    # measures the step at the clocks a training run sees and not the ramp.  Then the --warmup steps, then the window.
+    for _ in range(2000):
+        enc.learn(x, sync=False, global_count=gcount)
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         enc.learn(x, sync=False, global_count=gcount)
     dt = timed_window(args.steps)                       # THE timed region: exactly --steps steps
