@@ -1162,6 +1162,21 @@ __device__ __forceinline__ void car_reduce_block(const CarReduce& R, int blk, in
 }
 
 // ------------------------------------------------------------------ backward
+// One 16x16 output block as mt::wave_mma16 computes it (same two accumulation chains, same order), with the B
+// operand already in registers: b[s] = B(4 s + lane / 16, lane % 16).
+template <int K, int ASI, int ASK>
+__device__ __forceinline__ f32x4 wave_mma16_breg(const float* a, const float (&b)[K / 4], int lane, float init) {
+  static_assert(K % 8 == 0, "K must be a multiple of 8");
+  const float* ap = a + (lane & 15) * ASI + (lane >> 4) * ASK;
+  f32x4 c0 = {init, init, init, init}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < K; k += 8) {
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[k * ASK], b[k / 4], c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(k + 4) * ASK], b[k / 4 + 1], c1, 0, 0, 0);
+  }
+  return c0 + c1;
+}
+
 // SINGLE: the grid covers every tile (one tile per workgroup, the case up to 8192 traffic lanes); a layer's
 // slab entries are then written right after the phase that completes them, under the later phases.
 // NT = 256, or 512 (with SINGLE only: the multi-tile form needs the full register file per wave): four more
@@ -1841,6 +1856,7 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
     w4s[tid] = p_w4;
   }
   if (tid == 0) b4s[0] = p_b4;
+  if (tid < ST_WAVES) b4s[8 + tid] = 0.f;               // first_lane[] of the car rounds
   commit_cars16(car0);
   if (blockIdx.x == 0 && tid < 64) g.aux[128 + tid] = tid < 32 ? (g.params + g.ow[LOC])[tid] : (g.params + g.ob[LOC])[tid - 32];
   lds_barrier();
@@ -2039,6 +2055,20 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
     float p_t[8];
 #pragma unroll
     for (int blk = 0; blk < 8; ++blk) p_t[blk] = bs[FB_P + 16 * blk + j];
+    // S += a round's tiles, in tile order: a thread owns one traffic lane and four columns.  Each wave has left
+    // the first traffic lane of its car tile in first_lane[]; a tile that holds no row of the thread's lane is read
+    // at row 0 and not added, so that the eight reads are independent of one another.
+    float* first_lane = b4s + 8;
+    auto add_round_to_S = [&](int nw) {
+      const int rr = tid >> 5, c4 = 4 * (tid & 31);
+#pragma unroll
+      for (int u = 0; u < ST_WAVES; ++u) {
+        const int s = rr - (int)first_lane[u];
+        const bool ok = u < nw && s >= 0 && s < g.R;
+        const float4 e = *reinterpret_cast<const float4*>(ovl + FO_WAVE0 + u * CAR_WAVE_FLOATS + (ok ? s : 0) * 128 + c4);
+        S4.x += ok ? e.x : 0.f; S4.y += ok ? e.y : 0.f; S4.z += ok ? e.z : 0.f; S4.w += ok ? e.w : 0.f;
+      }
+    };
     for (int c_lo = 0; c_lo < ntiles; c_lo += ST_WAVES) {
       const int nw = min(ST_WAVES, ntiles - c_lo);      // waves with a car tile in this round
       const int ct = c_lo + wave;
@@ -2070,6 +2100,7 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
           for (int blk = 0; blk < 8; ++blk) f1[blk][e] = up[16 * blk];
         }
         const int b_first = __builtin_amdgcn_readfirstlane(in_b);
+        if (lane == 0) first_lane[wave] = (float)b_first;
 #pragma unroll
         for (int e = 0; e < 4; ++e) ind[e] = (b_k[e] >= 0 && b_k[e] - b_first == j) ? 1.f : 0.f;
         in_v = lv.y;
@@ -2203,32 +2234,52 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
       HHRL_STAMP(3, 19);
       lds_barrier();
       HHRL_STAMP(3, 20);
-      // ---- S += the round's tiles, in tile order: a thread owns one traffic lane and four columns
-      {
-        const int rr = tid >> 5, c4 = 4 * (tid & 31);
-        for (int u = 0; u < nw; ++u) {
-          const int s = rr - (int)((unsigned)((c_lo + u) * CAR_TILE) / (unsigned)g.N);
-          if (s >= 0 && s < g.R) {
-            const float4 e = *reinterpret_cast<const float4*>(ovl + FO_WAVE0 + u * CAR_WAVE_FLOATS + s * 128 + c4);
-            S4.x += e.x; S4.y += e.y; S4.z += e.z; S4.w += e.w;
-          }
-        }
-      }
+      // With one tile per workgroup the last round's sums are added after the loop, under the requests for the
+      // operands of the lane backward.
+      if (SINGLE && c_lo + ST_WAVES >= ntiles) break;
+      add_round_to_S(nw);
       lds_barrier();                                   // the image blocks are free for the next round
     }
     HHRL_STAMP(3, 5);
-    if (SINGLE) write_func2();
     // ---- the weight images are requested again (they are in L2); S takes U's place meanwhile.  The thread index
     //      goes through an opaque copy, so that the addresses are formed again here instead of being kept in
     //      registers (or spilled) since the prologue.
     int tid_b = tid;
     asm volatile("" : "+v"(tid_b));
-    request_weights(tid_b);
     float w0r[32];                                       // func.0's columns for d2 as the B operand of dd2 = S A (waves 0, 1)
     if (wave < 2) {
       const float* src = (g.params + g.ow[FUNC0]) + q * 64 + 16 * wave + j;
 #pragma unroll
       for (int s2 = 0; s2 < 32; ++s2) w0r[s2] = src[s2 * 256];
+    }
+    // With one tile per workgroup no forward pass follows, and every weight matrix is the B operand of exactly one
+    // product of the lane backward, in its own row-major orientation: B(k = output, j = input).  Each wave then
+    // asks for its operand columns directly (they are in L2), a phase or two before the product that uses them,
+    // and the images in LDS are not written again.  Where the zero-padded image had no weight the request goes to
+    // the matrix's first element instead (no branches, and no select that would wait for the value here): those
+    // operand entries meet zero columns of dml (heads) or produce columns of dz that nothing reads (decoder.0).
+    float bDec2r[8], bDec0r[8], bHeadr[8], bRho2r[16], bRho0r[32], bPhi2r[8];
+    if (SINGLE) {
+      const int lane_b = tid_b & 63, wave_b = tid_b >> 6, jb = lane_b & 15, qb = lane_b >> 4;
+      const float* s2 = (g.params + g.ow[DEC2]) + qb * 128 + 16 * wave_b + jb;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) bDec2r[s] = s2[s * 4 * 128];
+      if (wave_b < 4) {
+        const bool in0 = jb < gd;
+        const float* s0 = (g.params + g.ow[DEC0]) + (in0 ? (32 * wave_b + qb) * gd + jb : 0);
+        const int col = 16 * wave_b + jb;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          bDec0r[s] = s0[in0 ? s * 4 * gd : 0];
+          const int k = 4 * s + qb;
+          const int at = k < gd ? g.ow[MEAN] + k * 64 + col : g.ow[LOGVAR] + (k < 2 * gd ? (k - gd) * 64 + col : 0);
+          bHeadr[s] = g.params[at];
+        }
+      }
+      write_func2();
+      if (ntiles > 0) add_round_to_S(ntiles - (ntiles - 1) / ST_WAVES * ST_WAVES);
+    } else {
+      request_weights(tid_b);
     }
     {
       float* p = Iu + (tid >> 5) * 129 + 4 * (tid & 31);
@@ -2240,6 +2291,9 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
     // ================================================================= per-lane backward
     // ---- func.0, the part shared by a lane's cars: dd2 = S A (waves 0, 1), dA[128][32] += S^T d2 (row block `wave`)
     {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) aF0[cb] = wave_mma16<16, 1, 129, 33, 1>(Iu + 16 * wave, Id2 + 16 * cb, lane, aF0[cb]);
+      if (SINGLE) write_f0();
       if (wave < 2) {
         const float* ap = Iu + j * 129 + q;
         f32x4 c0 = zero4, c1 = zero4;
@@ -2250,20 +2304,25 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
         }
         store_block16<33>(Itmp, 0, 16 * wave, c0 + c1, lane);
       }
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) aF0[cb] = wave_mma16<16, 1, 129, 33, 1>(Iu + 16 * wave, Id2 + 16 * cb, lane, aF0[cb]);
     }
     HHRL_STAMP(3, 31);
-    if (SINGLE) write_f0();
     lds_barrier();
-    commit_weights(tid_b);                               // over S (consumed) and the car images
-    lds_barrier();
+    if (!SINGLE) {
+      commit_weights(tid_b);                             // over S (consumed) and the car images
+      lds_barrier();
+    }
     HHRL_STAMP(3, 6);
     // ---- decoder.2 backward: dW[32][128] += dd2^T d1 (column block `wave`), db, dd1 = (dd2 W) o relu'(d1) in place
     {
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) aDec2[rb] = wave_mma16<16, 1, 33, 129, 1>(Itmp + 16 * rb, Id1 + 16 * wave, lane, aDec2[rb]);
-      const f32x4 d = wave_mma16<32, 33, 1, 129, 1>(Itmp, ovl + LW_DEC2 + 16 * wave, lane, 0.f);
+      if (SINGLE) {
+        const float* s = (g.params + g.ow[RHO2]) + q * 128 + 16 * wave + j;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) bRho2r[u] = s[u * 4 * 128];
+      }
+      const f32x4 d = SINGLE ? wave_mma16_breg<32, 33, 1>(Itmp, bDec2r, lane, 0.f)
+                             : wave_mma16<32, 33, 1, 129, 1>(Itmp, ovl + LW_DEC2 + 16 * wave, lane, 0.f);
       wave_sync();
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -2279,7 +2338,8 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
     {
       aDec0 = wave_mma16<16, 1, 129, 17, 1>(Id1 + 16 * wave, Iz, lane, aDec0);
       if (wave < 4) {
-        const f32x4 c = wave_mma16<32, 129, 1, 17, 1>(Id1 + 32 * wave, ovl + LW_DEC0 + 32 * wave * 17, lane, 0.f);
+        const f32x4 c = SINGLE ? wave_mma16_breg<32, 129, 1>(Id1 + 32 * wave, bDec0r, lane, 0.f)
+                               : wave_mma16<32, 129, 1, 17, 1>(Id1 + 32 * wave, ovl + LW_DEC0 + 32 * wave * 17, lane, 0.f);
         store_block16<17>(ovl + FO_SPARE + wave * 16 * 17, 0, 0, c, lane);
       }
       if (tid >= 256 && tid < 384) bDec0 += colsum16(Id1, 129, tid - 256);
@@ -2311,7 +2371,9 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
     {
       aHead = wave_mma16<16, 1, 33, 65, 1>(Idml + 16 * (wave >> 2), Ir2 + 16 * (wave & 3), lane, aHead);
       f32x4 d = zero4;
-      if (wave < 4) d = wave_mma16<32, 33, 1, 65, 1>(Idml, ovl + LW_HEAD + 16 * wave, lane, 0.f);
+      if (wave < 4)
+        d = SINGLE ? wave_mma16_breg<32, 33, 1>(Idml, bHeadr, lane, 0.f)
+                   : wave_mma16<32, 33, 1, 65, 1>(Idml, ovl + LW_HEAD + 16 * wave, lane, 0.f);
       if (tid >= 256 && tid < 288) bHead += colsum16(Idml, 33, tid - 256);
       lds_barrier();
       if (wave < 4) store_block16<65>(Ir2, 0, 16 * wave, d, lane);
@@ -2323,7 +2385,18 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
     {
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb) aRho2[rb] = wave_mma16<16, 1, 65, 129, 1>(Ir2 + 16 * rb, Ir1 + 16 * wave, lane, aRho2[rb]);
-      const f32x4 d = wave_mma16<64, 65, 1, 129, 1>(Ir2, ovl + LW_RHO2 + 16 * wave, lane, 0.f);
+      if (SINGLE && wave < 2) {
+        const float* s = (g.params + g.ow[RHO0]) + q * 32 + 16 * wave + j;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) bRho0r[u] = s[u * 4 * 32];
+      }
+      if (SINGLE && wave == 2) {
+        const float* s = (g.params + g.ow[PHI2]) + q * 16 + j;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) bPhi2r[u] = s[u * 4 * 16];
+      }
+      const f32x4 d = SINGLE ? wave_mma16_breg<64, 65, 1>(Ir2, bRho2r, lane, 0.f)
+                             : wave_mma16<64, 65, 1, 129, 1>(Ir2, ovl + LW_RHO2 + 16 * wave, lane, 0.f);
       wave_sync();
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -2340,7 +2413,8 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) aRho0[cb] = wave_mma16<16, 1, 129, 33, 1>(Ir1 + 16 * wave, Ipool + 16 * cb, lane, aRho0[cb]);
       if (wave < 2) {
-        const f32x4 c = wave_mma16<128, 129, 1, 33, 1>(Ir1, ovl + LW_RHO0 + 16 * wave, lane, 0.f);
+        const f32x4 c = SINGLE ? wave_mma16_breg<128, 129, 1>(Ir1, bRho0r, lane, 0.f)
+                               : wave_mma16<128, 129, 1, 33, 1>(Ir1, ovl + LW_RHO0 + 16 * wave, lane, 0.f);
         store_block16<33>(Iml, 0, 16 * wave, c, lane);
       }
       if (tid >= 256 && tid < 384) bRho0 += colsum16(Ir1, 129, tid - 256);
@@ -2354,7 +2428,8 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
       if (wave < 2) {
         aPhi2 = wave_mma16<16, 1, 33, 33, 1>(Iml + 16 * wave, Ih1, lane, aPhi2);
       } else if (wave == 2) {
-        const f32x4 c = wave_mma16<32, 33, 1, 17, 1>(Iml, ovl + LW_PHI2, lane, 0.f);
+        const f32x4 c = SINGLE ? wave_mma16_breg<32, 33, 1>(Iml, bPhi2r, lane, 0.f)
+                               : wave_mma16<32, 33, 1, 17, 1>(Iml, ovl + LW_PHI2, lane, 0.f);
         store_block16<33>(Itmp, 0, 0, c, lane);
       }
       if (tid >= 256 && tid < 288) bPhi2 += (float)g.N * colsum16(Iml, 33, tid - 256);
