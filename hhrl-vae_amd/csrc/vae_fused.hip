@@ -732,8 +732,14 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_forward_kernel(LaneArgs g) {
       const int b = row0 + rr;
       float s = 0.f;
       if (b < g.B) {
-        const float* x = staged ? lds + LI_CARS + rr * g.N * 2 : g.data + (long)b * g.N * 2;
-        for (int n = 0; n < g.N; ++n) s += fmaxf(wa * x[2 * n] + wb * x[2 * n + 1] + bb, 0.f);
+        // two loops, so that each reads through a pointer of a known address space
+        if (staged) {
+          const float* x = lds + LI_CARS + rr * g.N * 2;
+          for (int n = 0; n < g.N; ++n) s += fmaxf(wa * x[2 * n] + wb * x[2 * n + 1] + bb, 0.f);
+        } else {
+          const float* x = g.data + (long)b * g.N * 2;
+          for (int n = 0; n < g.N; ++n) s += fmaxf(wa * x[2 * n] + wb * x[2 * n + 1] + bb, 0.f);
+        }
       }
       Ih1[rr * 33 + k] = s;
     }
@@ -1513,11 +1519,14 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
         const int b = row0 + rr;
         float a0 = 0.f, a1 = 0.f, c = 0.f;
         if (b < g.B) {
-          const float* x = staged ? lds + LI_CARS + rr * g.N * 2 : g.data + (long)b * g.N * 2;
-          for (int n = 0; n < g.N; ++n) {
-            const float x0 = x[2 * n], x1 = x[2 * n + 1];
-            if (wa * x0 + wb * x1 + bb > 0.f) { a0 += x0; a1 += x1; c += 1.f; }
-          }
+          auto walk = [&](const float* x) {
+            for (int n = 0; n < g.N; ++n) {
+              const float x0 = x[2 * n], x1 = x[2 * n + 1];
+              if (wa * x0 + wb * x1 + bb > 0.f) { a0 += x0; a1 += x1; c += 1.f; }
+            }
+          };
+          if (staged) walk(lds + LI_CARS + rr * g.N * 2);
+          else walk(g.data + (long)b * g.N * 2);
         }
         const float t = Itmp[rr * 33 + k];
         red[rr * 49 + k] = t * a0;
@@ -1969,8 +1978,14 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
       const float wa = bs[FB_PHI0 + 2 * k], wb = bs[FB_PHI0 + 2 * k + 1], bb = bs[FB_PHI0 + 32 + k];
       float s = 0.f;
       if (rr < nlanes) {
-        const float* x = staged ? Icars + rr * g.N * 2 : g.data + (car_base + (long)rr * g.N) * 2;
-        for (int n = 0; n < g.N; ++n) s += fmaxf(wa * x[2 * n] + wb * x[2 * n + 1] + bb, 0.f);
+        // two loops, so that each reads through a pointer of a known address space
+        if (staged) {
+          const float* x = Icars + rr * g.N * 2;
+          for (int n = 0; n < g.N; ++n) s += fmaxf(wa * x[2 * n] + wb * x[2 * n + 1] + bb, 0.f);
+        } else {
+          const float* x = g.data + (car_base + (long)rr * g.N) * 2;
+          for (int n = 0; n < g.N; ++n) s += fmaxf(wa * x[2 * n] + wb * x[2 * n + 1] + bb, 0.f);
+        }
       }
       Ih1[rr * 33 + k] = s;
     }
@@ -2084,8 +2099,10 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
         const int crow = ct * CAR_TILE + j;             // car within the lane tile
         const bool valid = crow < ncars;
         float2 lv = make_float2(0.f, 0.f);
-        if (valid) lv = staged ? *reinterpret_cast<const float2*>(Icars + 2 * crow)
-                               : *reinterpret_cast<const float2*>(g.data + 2 * (car_base + crow));
+        if (valid) {
+          if (staged) lv = *reinterpret_cast<const float2*>(Icars + 2 * crow);
+          else lv = *reinterpret_cast<const float2*>(g.data + 2 * (car_base + crow));
+        }
         in_b = valid ? (int)((unsigned)crow / (unsigned)g.N) : -1;     // traffic lane within the tile, 0..15
         int b_i[4], b_k[4];
 #pragma unroll
@@ -2445,11 +2462,14 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
         const float wa = bs[FB_PHI0 + 2 * k], wb = bs[FB_PHI0 + 2 * k + 1], bb = bs[FB_PHI0 + 32 + k];
         float a0 = 0.f, a1 = 0.f, c = 0.f;
         if (rr < nlanes) {
-          const float* x = staged ? Icars + rr * g.N * 2 : g.data + (car_base + (long)rr * g.N) * 2;
-          for (int n = 0; n < g.N; ++n) {
-            const float x0 = x[2 * n], x1 = x[2 * n + 1];
-            if (wa * x0 + wb * x1 + bb > 0.f) { a0 += x0; a1 += x1; c += 1.f; }
-          }
+          auto walk = [&](const float* x) {
+            for (int n = 0; n < g.N; ++n) {
+              const float x0 = x[2 * n], x1 = x[2 * n + 1];
+              if (wa * x0 + wb * x1 + bb > 0.f) { a0 += x0; a1 += x1; c += 1.f; }
+            }
+          };
+          if (staged) walk(Icars + rr * g.N * 2);
+          else walk(g.data + (car_base + (long)rr * g.N) * 2);
         }
         const float t = Itmp[rr * 33 + k];
         red[rr * 49 + k] = t * a0;
