@@ -37,8 +37,12 @@ using namespace mt;
 #ifdef HHRL_STAMPS
 __device__ long long g_stamps[4][64];
 #define HHRL_STAMP(k, i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[k][i] = clock64(); } while (0)
+// start and end of every workgroup of the one-launch step: constant-rate counter and shader clock
+__device__ long long g_wg_span[256][4];
+#define HHRL_WG_SPAN(i) do { if (threadIdx.x == 0 && blockIdx.x < 256) { g_wg_span[blockIdx.x][i] = wall_clock64(); g_wg_span[blockIdx.x][2 + i] = clock64(); } } while (0)
 #else
 #define HHRL_STAMP(k, i) do { } while (0)
+#define HHRL_WG_SPAN(i) do { } while (0)
 #endif
 
 // parameter order == Encoder.parameters() order (weight, bias interleaved)
@@ -78,6 +82,12 @@ struct CarArgs {
 
 // A wave owns a tile of 16 cars; eight waves per workgroup, two per SIMD, so that one wave's element-wise
 // phases and LDS round trips run under the other's matrix instructions.
+// A workgroup's slab entries and the activation images that one kernel of the four-launch form leaves for the
+// next go through the L2 as they are produced (store_through), so that the end of the kernel does not wait for
+// their write-back.
+__device__ __forceinline__ void slab_put(float* p, float v) { store_through(p, v); }
+__device__ __forceinline__ void stream_put(float4* p, const float4& v) { store_through(p, v); }
+
 constexpr int CAR_TILE = 16, CAR_WAVES = 8, CAR_THREADS = 64 * CAR_WAVES;
 constexpr int CAR_W2 = 0;                          // [32][129]
 constexpr int CAR_SMALL = CAR_W2 + 32 * 129;       // b2[32] w4[32] b4[1]
@@ -286,7 +296,7 @@ __global__ __launch_bounds__(CAR_THREADS, 1) void vae_car_fwd_bwd_kernel(CarArgs
       for (int e = 0; e < 4; ++e) {
         if (4 * q + e < g.R) {
 #pragma unroll
-          for (int blk = 0; blk < 8; ++blk) dst[(4 * q + e) * 128 + 16 * blk] = P[blk][e];
+          for (int blk = 0; blk < 8; ++blk) slab_put(&dst[(4 * q + e) * 128 + 16 * blk], P[blk][e]);
         }
       }
     }
@@ -374,23 +384,23 @@ __global__ __launch_bounds__(CAR_THREADS, 1) void vae_car_fwd_bwd_kernel(CarArgs
                     add4(add4(qv[4 * S4 + i], qv[5 * S4 + i]), add4(qv[6 * S4 + i], qv[7 * S4 + i])));
     }
   } else {
-    for (int i = tid; i < 4096; i += CAR_THREADS) slab[g.off.w[FUNC2] + i] = all8(B_W2 + i);
+    for (int i = tid; i < 4096; i += CAR_THREADS) slab_put(&slab[g.off.w[FUNC2] + i], all8(B_W2 + i));
   }
   float* fin = lds + CAR_FIN;
   if (tid < 128) {
     const float sv = all8(B_S + tid);
     fin[tid] = sv;
-    slab[g.off.w[FUNC0] + tid * 64 + 32] = sv;       // s[o] travels in the first position of row o that no sum uses
+    slab_put(&slab[g.off.w[FUNC0] + tid * 64 + 32], sv);       // s[o] travels in the first position of row o that no sum uses
   } else if (tid < 256) {
     const float dv = all8(B_B0 + tid - 128);
     fin[tid] = dv;
-    slab[g.off.b[FUNC0] + tid - 128] = dv;
+    slab_put(&slab[g.off.b[FUNC0] + tid - 128], dv);
   } else if (tid < 288) {
-    slab[g.off.b[FUNC2] + tid - 256] = all8(B_B2 + tid - 256);
+    slab_put(&slab[g.off.b[FUNC2] + tid - 256], all8(B_B2 + tid - 256));
   } else if (tid < 320) {
-    slab[g.off.w[FUNC4] + tid - 288] = all8(B_W4 + tid - 288);
+    slab_put(&slab[g.off.w[FUNC4] + tid - 288], all8(B_W4 + tid - 288));
   } else if (tid == 320) {
-    slab[g.off.b[FUNC4]] = all8(B_B4);
+    slab_put(&slab[g.off.b[FUNC4]], all8(B_B4));
   } else if (tid == 321) {
     g.loss_part[blockIdx.x] = all8(B_LOSS);
   }
@@ -414,7 +424,7 @@ __global__ __launch_bounds__(CAR_THREADS, 1) void vae_car_fwd_bwd_kernel(CarArgs
     float sum = 0.f;
 #pragma unroll
     for (int og = 0; og < 16; og += 4) sum += (pp[og * 64] + pp[(og + 1) * 64]) + (pp[(og + 2) * 64] + pp[(og + 3) * 64]);
-    slab[(tid < 32 ? g.off.w[LOC] + tid : g.off.b[LOC] + tid - 32)] = sum;
+    slab_put(&slab[(tid < 32 ? g.off.w[LOC] + tid : g.off.b[LOC] + tid - 32)], sum);
   }
   HHRL_STAMP(0, 12);
 }
@@ -843,7 +853,7 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_forward_kernel(LaneArgs g) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int rr = drow(i, lane >> 5);
-        if (row0 + rr < g.B) dst[rr * 128] = acc[i];
+        if (row0 + rr < g.B) slab_put(&dst[rr * 128], acc[i]);
       }
     }
     HHRL_STAMP(1, 11);
@@ -853,7 +863,7 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_forward_kernel(LaneArgs g) {
 #pragma unroll
       for (int u = 0; u < (ACT_V4 + NT - 1) / NT; ++u) {
         const int i4 = u * NT + tid;
-        if (i4 < ACT_V4) dst[i4] = src[i4];
+        if (i4 < ACT_V4) stream_put(&dst[i4], src[i4]);
       }
     }
     __syncthreads();
@@ -1235,7 +1245,7 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = drow(i, h);
-      if (row < row_lim && col < col_lim) slab[base + (long)row * ld + col] = t[i];
+      if (row < row_lim && col < col_lim) slab_put(&slab[base + (long)row * ld + col], t[i]);
     }
   };
 
@@ -1244,11 +1254,11 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
   };
   auto write_dec2 = [&]() {
     if (mat) put_tile(g.off.w[DEC2], 128, 32, 32 * wave, 128, aDec2);
-    if (owns(bt, 32)) slab[g.off.b[DEC2] + bt] = bDec2;
+    if (owns(bt, 32)) slab_put(&slab[g.off.b[DEC2] + bt], bDec2);
   };
   auto write_dec0 = [&]() {
     if (mat) put_tile(g.off.w[DEC0] + (long)32 * wave * gd, gd, 32, 0, gd, aDec0);
-    if (owns(bt_dec0, 128)) slab[g.off.b[DEC0] + bt_dec0] = bDec0;
+    if (owns(bt_dec0, 128)) slab_put(&slab[g.off.b[DEC0] + bt_dec0], bDec0);
   };
   auto write_heads = [&]() {
     if (wave < 2) {
@@ -1268,8 +1278,8 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
         }
       }
     }
-    if (owns(bt, gd)) slab[g.off.b[MEAN] + bt] = bHead;
-    else if (owns(bt, 2 * gd)) slab[g.off.b[LOGVAR] + bt - gd] = bHead;
+    if (owns(bt, gd)) slab_put(&slab[g.off.b[MEAN] + bt], bHead);
+    else if (owns(bt, 2 * gd)) slab_put(&slab[g.off.b[LOGVAR] + bt - gd], bHead);
   };
   auto write_rho2 = [&]() {
     if (mat) {
@@ -1277,15 +1287,15 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
       put_tile(g.off.w[RHO2] + (long)32 * it * 128, 128, 32, 32 * jt0, 128, aRho2a);
       put_tile(g.off.w[RHO2] + (long)32 * it * 128, 128, 32, 32 * (jt0 + 1), 128, aRho2b);
     }
-    if (owns(bt, 64)) slab[g.off.b[RHO2] + bt] = bRho2;
+    if (owns(bt, 64)) slab_put(&slab[g.off.b[RHO2] + bt], bRho2);
   };
   auto write_rho0 = [&]() {
     if (mat) put_tile(g.off.w[RHO0] + (long)32 * wave * 32, 32, 32, 0, 32, aRho0);
-    if (owns(bt, 128)) slab[g.off.b[RHO0] + bt] = bRho0;
+    if (owns(bt, 128)) slab_put(&slab[g.off.b[RHO0] + bt], bRho0);
   };
   auto write_phi2 = [&]() {
     if (wave == 0) put_tile(g.off.w[PHI2], 16, 32, 0, 16, aPhi2);
-    if (owns(bt_phi2, 32)) slab[g.off.b[PHI2] + bt_phi2] = bPhi2;
+    if (owns(bt_phi2, 32)) slab_put(&slab[g.off.b[PHI2] + bt_phi2], bPhi2);
   };
 
   int tile = blockIdx.x;
@@ -1554,11 +1564,11 @@ __global__ __launch_bounds__(NT, 1) void vae_lane_backward_kernel(LaneArgs g, Ca
     write_phi2();
   }
   if (tid < 16) {
-    slab[g.off.w[PHI0] + 2 * tid] = gPhi0a;
+    slab_put(&slab[g.off.w[PHI0] + 2 * tid], gPhi0a);
   } else if (tid < 32) {
-    slab[g.off.w[PHI0] + 2 * (tid - 16) + 1] = gPhi0b;
+    slab_put(&slab[g.off.w[PHI0] + 2 * (tid - 16) + 1], gPhi0b);
   } else if (tid < 48) {
-    slab[g.off.b[PHI0] + tid - 32] = gPhi0c;
+    slab_put(&slab[g.off.b[PHI0] + tid - 32], gPhi0c);
   }
   // KL partial of this workgroup
   klacc = wave_sum(klacc);
@@ -1757,6 +1767,7 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
   float* dpre = wl + CAR_ROW;
   const bool staged = g.N <= STAGE_MAX_CARS;
   HHRL_STAMP(3, 0);
+  HHRL_WG_SPAN(0);
 
   // ---- requests of the prologue: everything is asked for before the first LDS write
   RegsP<NT> rP;
@@ -1897,7 +1908,7 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int row = row0 + 4 * q + e;
-      if (row < row_lim && col < col_lim) slab[base + (long)row * ld + col] = t[e];
+      if (row < row_lim && col < col_lim) slab_put(&slab[base + (long)row * ld + col], t[e]);
     }
   };
   const int bt = tid - 256;                            // owner index of the bias-gradient column sums
@@ -1908,11 +1919,11 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
   auto write_dec2 = [&]() {
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) put16(g.ow[DEC2], 128, 16 * rb, 32, 16 * wave, 128, aDec2[rb]);
-    if (bt >= 0 && bt < 32) slab[g.ob[DEC2] + bt] = bDec2;
+    if (bt >= 0 && bt < 32) slab_put(&slab[g.ob[DEC2] + bt], bDec2);
   };
   auto write_dec0 = [&]() {
     put16(g.ow[DEC0], gd, 16 * wave, 128, 0, gd, aDec0);
-    if (bt >= 0 && bt < 128) slab[g.ob[DEC0] + bt] = bDec0;
+    if (bt >= 0 && bt < 128) slab_put(&slab[g.ob[DEC0] + bt], bDec0);
   };
   auto write_heads = [&]() {
     // rows < g belong to to_mean, rows g..2g-1 to to_logvar
@@ -1920,34 +1931,81 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int row = 16 * (wave >> 2) + 4 * q + e;
-      if (row < gd) slab[g.ow[MEAN] + (long)row * 64 + col] = aHead[e];
-      else if (row < 2 * gd) slab[g.ow[LOGVAR] + (long)(row - gd) * 64 + col] = aHead[e];
+      if (row < gd) slab_put(&slab[g.ow[MEAN] + (long)row * 64 + col], aHead[e]);
+      else if (row < 2 * gd) slab_put(&slab[g.ow[LOGVAR] + (long)(row - gd) * 64 + col], aHead[e]);
     }
-    if (bt >= 0 && bt < gd) slab[g.ob[MEAN] + bt] = bHead;
-    else if (bt >= 0 && bt < 2 * gd) slab[g.ob[LOGVAR] + bt - gd] = bHead;
+    if (bt >= 0 && bt < gd) slab_put(&slab[g.ob[MEAN] + bt], bHead);
+    else if (bt >= 0 && bt < 2 * gd) slab_put(&slab[g.ob[LOGVAR] + bt - gd], bHead);
   };
   auto write_rho2 = [&]() {
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) put16(g.ow[RHO2], 128, 16 * rb, 64, 16 * wave, 128, aRho2[rb]);
-    if (bt >= 0 && bt < 64) slab[g.ob[RHO2] + bt] = bRho2;
+    if (bt >= 0 && bt < 64) slab_put(&slab[g.ob[RHO2] + bt], bRho2);
   };
   auto write_rho0 = [&]() {
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) put16(g.ow[RHO0], 32, 16 * wave, 128, 16 * cb, 32, aRho0[cb]);
-    if (bt >= 0 && bt < 128) slab[g.ob[RHO0] + bt] = bRho0;
+    if (bt >= 0 && bt < 128) slab_put(&slab[g.ob[RHO0] + bt], bRho0);
   };
   auto write_phi2 = [&]() {
     if (wave < 2) put16(g.ow[PHI2], 16, 16 * wave, 32, 0, 16, aPhi2);
-    if (bt >= 0 && bt < 32) slab[g.ob[PHI2] + bt] = bPhi2;
+    if (bt >= 0 && bt < 32) slab_put(&slab[g.ob[PHI2] + bt], bPhi2);
   };
   auto write_phi0 = [&]() {
-    if (tid < 16) slab[g.ow[PHI0] + 2 * tid] = gPhi0;
-    else if (tid < 32) slab[g.ow[PHI0] + 2 * (tid - 16) + 1] = gPhi0;
-    else if (tid < 48) slab[g.ob[PHI0] + tid - 32] = gPhi0;
+    if (tid < 16) slab_put(&slab[g.ow[PHI0] + 2 * tid], gPhi0);
+    else if (tid < 32) slab_put(&slab[g.ow[PHI0] + 2 * (tid - 16) + 1], gPhi0);
+    else if (tid < 48) slab_put(&slab[g.ob[PHI0] + tid - 32], gPhi0);
   };
   auto write_func2 = [&]() {
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) put16(g.ow[FUNC2], 128, 16 * rb, 32, 16 * wave, 128, dW2a[rb]);
+  };
+
+  // The waves' small sums meet in LDS, Q1 floats per wave: db0[128] s[128] db2[32] w4[32] b4 loss kl.  With one tile
+  // per workgroup they are final when the car rounds end and go there at once (into the part of each wave's image
+  // block that held its func.2 activations, which nothing writes afterwards), so that they hold no registers during
+  // the lane backward; otherwise they are parked at the end, over the dead images.
+  constexpr int Q1 = 328;
+  constexpr int B_B0 = 0, B_S = 128, B_B2 = 256, B_W4 = 288, B_B4 = 320, B_LOSS = 321, B_KL = 322;
+  static_assert(Q1 <= 16 * 33, "a wave's sums fit its func.2 image");
+  static_assert(FO_WAVE0 + (ST_WAVES - 1) * CAR_WAVE_FLOATS + CAR_F2 >= FO_SPARE + 4 * 16 * 17,
+                "the last wave's parked sums lie behind the partial products of dz");
+  static_assert(FO_WAVE0 + (ST_WAVES - 2) * CAR_WAVE_FLOATS + CAR_F2 + Q1 <= FO_SPARE,
+                "the other waves' parked sums lie before the partial products of dz");
+  constexpr int QS = SINGLE ? CAR_WAVE_FLOATS : Q1;
+  float* cmb = SINGLE ? ovl + FO_WAVE0 + CAR_F2 : ovl;
+  auto park_car_sums = [&]() {
+#pragma unroll
+    for (int blk = 0; blk < 8; ++blk) {
+      db0[blk] += __shfl_xor(db0[blk], 16, 64);
+      db0[blk] += __shfl_xor(db0[blk], 32, 64);
+      sacc[blk] += __shfl_xor(sacc[blk], 16, 64);
+      sacc[blk] += __shfl_xor(sacc[blk], 32, 64);
+    }
+    w4acc += __shfl_xor(w4acc, 32, 64);
+    db2acc += __shfl_xor(db2acc, 32, 64);
+    b4acc = wave_sum(b4acc);
+    lossacc = wave_sum(lossacc);
+    float* mine = cmb + wave * QS;
+    if (q == 0) {
+#pragma unroll
+      for (int blk = 0; blk < 8; ++blk) {
+        mine[B_B0 + 16 * blk + j] = db0[blk];
+        mine[B_S + 16 * blk + j] = sacc[blk];
+      }
+    }
+    if (h32 == 0) {
+      mine[B_B2 + r32] = db2acc;
+      mine[B_W4 + r32] = w4acc;
+    }
+    if (lane == 0) {
+      mine[B_B4] = b4acc;
+      mine[B_LOSS] = lossacc;
+    }
+  };
+  auto park_kl = [&]() {
+    klacc = wave_sum(klacc);
+    if (lane == 0) cmb[wave * QS + B_KL] = klacc;
   };
 
   int tile = blockIdx.x;
@@ -2294,6 +2352,7 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
         }
       }
       write_func2();
+      park_car_sums();
       if (ntiles > 0) add_round_to_S(ntiles - (ntiles - 1) / ST_WAVES * ST_WAVES);
     } else {
       request_weights(tid_b);
@@ -2382,6 +2441,7 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
       }
       Idml[rr * 33 + c] = outv;
     }
+    if (SINGLE) park_kl();
     lds_barrier();
     HHRL_STAMP(3, 34);
     // ---- heads backward: dW[2g][64] += dml^T r2 (block (wave / 4, wave % 4)), db, dr2 = dml W (waves 0..3; replaces r2)
@@ -2508,60 +2568,31 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
     write_func2();
   }
   // ---- the per-car layers' small sums: lane groups first, then the eight waves through LDS in a fixed order
-#pragma unroll
-  for (int blk = 0; blk < 8; ++blk) {
-    db0[blk] += __shfl_xor(db0[blk], 16, 64);
-    db0[blk] += __shfl_xor(db0[blk], 32, 64);
-    sacc[blk] += __shfl_xor(sacc[blk], 16, 64);
-    sacc[blk] += __shfl_xor(sacc[blk], 32, 64);
+  if (!SINGLE) {
+    park_car_sums();
+    park_kl();
+    lds_barrier();
   }
-  w4acc += __shfl_xor(w4acc, 32, 64);
-  db2acc += __shfl_xor(db2acc, 32, 64);
-  b4acc = wave_sum(b4acc);
-  lossacc = wave_sum(lossacc);
-  klacc = wave_sum(klacc);
-  constexpr int Q1 = 328;                               // db0[128] s[128] db2[32] w4[32] b4 loss kl
-  constexpr int B_B0 = 0, B_S = 128, B_B2 = 256, B_W4 = 288, B_B4 = 320, B_LOSS = 321, B_KL = 322;
-  float* cmb = ovl;                                      // every image in the shared region is dead
-  {
-    float* mine = cmb + wave * Q1;
-    if (q == 0) {
-#pragma unroll
-      for (int blk = 0; blk < 8; ++blk) {
-        mine[B_B0 + 16 * blk + j] = db0[blk];
-        mine[B_S + 16 * blk + j] = sacc[blk];
-      }
-    }
-    if (h32 == 0) {
-      mine[B_B2 + r32] = db2acc;
-      mine[B_W4 + r32] = w4acc;
-    }
-    if (lane == 0) {
-      mine[B_B4] = b4acc;
-      mine[B_LOSS] = lossacc;
-      mine[B_KL] = klacc;
-    }
-  }
-  lds_barrier();
   auto all8 = [&](int i) {
-    return ((cmb[i] + cmb[Q1 + i]) + (cmb[2 * Q1 + i] + cmb[3 * Q1 + i])) +
-           ((cmb[4 * Q1 + i] + cmb[5 * Q1 + i]) + (cmb[6 * Q1 + i] + cmb[7 * Q1 + i]));
+    return ((cmb[i] + cmb[QS + i]) + (cmb[2 * QS + i] + cmb[3 * QS + i])) +
+           ((cmb[4 * QS + i] + cmb[5 * QS + i]) + (cmb[6 * QS + i] + cmb[7 * QS + i]));
   };
-  float* fin = cmb + ST_WAVES * Q1;                      // s[128] | db0[128] | partial products [16][64]
+  // s[128] | db0[128] | partial products [16][64]
+  float* fin = SINGLE ? ovl : cmb + ST_WAVES * Q1;
   if (tid < 128) {
     const float sv = all8(B_S + tid);
     fin[tid] = sv;
-    slab[g.ow[FUNC0] + tid * 64 + 32] = sv;           // s[o] travels in the first position of row o that no sum uses
+    slab_put(&slab[g.ow[FUNC0] + tid * 64 + 32], sv);           // s[o] travels in the first position of row o that no sum uses
   } else if (tid < 256) {
     const float dv = all8(B_B0 + tid - 128);
     fin[tid] = dv;
-    slab[g.ob[FUNC0] + tid - 128] = dv;
+    slab_put(&slab[g.ob[FUNC0] + tid - 128], dv);
   } else if (tid < 288) {
-    slab[g.ob[FUNC2] + tid - 256] = all8(B_B2 + tid - 256);
+    slab_put(&slab[g.ob[FUNC2] + tid - 256], all8(B_B2 + tid - 256));
   } else if (tid < 320) {
-    slab[g.ow[FUNC4] + tid - 288] = all8(B_W4 + tid - 288);
+    slab_put(&slab[g.ow[FUNC4] + tid - 288], all8(B_W4 + tid - 288));
   } else if (tid == 320) {
-    slab[g.ob[FUNC4]] = all8(B_B4);
+    slab_put(&slab[g.ob[FUNC4]], all8(B_B4));
   } else if (tid == 321) {
     g.loss_part[blockIdx.x] = all8(B_LOSS);
   } else if (tid == 322) {
@@ -2587,9 +2618,10 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
     float sum = 0.f;
 #pragma unroll
     for (int og = 0; og < 16; og += 4) sum += (pp[og * 64] + pp[(og + 1) * 64]) + (pp[(og + 2) * 64] + pp[(og + 3) * 64]);
-    slab[(tid < 32 ? g.ow[LOC] + tid : g.ob[LOC] + tid - 32)] = sum;
+    slab_put(&slab[(tid < 32 ? g.ow[LOC] + tid : g.ob[LOC] + tid - 32)], sum);
   }
   HHRL_STAMP(3, 8);
+  HHRL_WG_SPAN(1);
 }
 
 // The same reduction for the one-launch step, where every column is summed over the same n slabs: 64
@@ -3106,6 +3138,9 @@ int hhrl_vae_decode(const float* params, const long* offsets, long n_flat, const
 // diagnostic builds only: copies the recorded clocks (4 kernels x 64 stamps) to the host
 int hhrl_debug_stamps(long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hhrl::vf::g_stamps), sizeof(long long) * 4 * 64);
+}
+int hhrl_debug_wg_spans(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hhrl::vf::g_wg_span), sizeof(long long) * 256 * 4);
 }
 #endif
 
