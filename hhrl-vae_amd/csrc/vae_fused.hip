@@ -2573,6 +2573,8 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
     park_kl();
     lds_barrier();
   }
+  // (the few hundred entries from here on are ordinary stores: written through, their acknowledgements would be
+  //  waited for at the very end of the workgroup)
   auto all8 = [&](int i) {
     return ((cmb[i] + cmb[QS + i]) + (cmb[2 * QS + i] + cmb[3 * QS + i])) +
            ((cmb[4 * QS + i] + cmb[5 * QS + i]) + (cmb[6 * QS + i] + cmb[7 * QS + i]));
@@ -2582,17 +2584,17 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
   if (tid < 128) {
     const float sv = all8(B_S + tid);
     fin[tid] = sv;
-    slab_put(&slab[g.ow[FUNC0] + tid * 64 + 32], sv);           // s[o] travels in the first position of row o that no sum uses
+    slab[g.ow[FUNC0] + tid * 64 + 32] = sv;           // s[o] travels in the first position of row o that no sum uses
   } else if (tid < 256) {
     const float dv = all8(B_B0 + tid - 128);
     fin[tid] = dv;
-    slab_put(&slab[g.ob[FUNC0] + tid - 128], dv);
+    slab[g.ob[FUNC0] + tid - 128] = dv;
   } else if (tid < 288) {
-    slab_put(&slab[g.ob[FUNC2] + tid - 256], all8(B_B2 + tid - 256));
+    slab[g.ob[FUNC2] + tid - 256] = all8(B_B2 + tid - 256);
   } else if (tid < 320) {
-    slab_put(&slab[g.ow[FUNC4] + tid - 288], all8(B_W4 + tid - 288));
+    slab[g.ow[FUNC4] + tid - 288] = all8(B_W4 + tid - 288);
   } else if (tid == 320) {
-    slab_put(&slab[g.ob[FUNC4]], all8(B_B4));
+    slab[g.ob[FUNC4]] = all8(B_B4);
   } else if (tid == 321) {
     g.loss_part[blockIdx.x] = all8(B_LOSS);
   } else if (tid == 322) {
@@ -2618,7 +2620,7 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
     float sum = 0.f;
 #pragma unroll
     for (int og = 0; og < 16; og += 4) sum += (pp[og * 64] + pp[(og + 1) * 64]) + (pp[(og + 2) * 64] + pp[(og + 3) * 64]);
-    slab_put(&slab[(tid < 32 ? g.ow[LOC] + tid : g.ob[LOC] + tid - 32)], sum);
+    slab[(tid < 32 ? g.ow[LOC] + tid : g.ob[LOC] + tid - 32)] = sum;
   }
   HHRL_STAMP(3, 8);
   HHRL_WG_SPAN(1);

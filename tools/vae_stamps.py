@@ -35,8 +35,8 @@ STEP = [(0, "start"), (1, "weights, W2, cars in LDS"), (2, "tile start"), (22, "
         (26, "heads"), (27, "reparam"), (28, "dec.0"), (3, "dec.2"), (4, "U = d2 A^T + q"),
         (10, "car: inputs, func.0"), (11, "car: func.2 fwd"), (12, "car: func.4 + err"), (13, "car: func.4 bwd"),
         (14, "car: df2 W2"), (15, "car: barrier 1"), (16, "car: dW2 across waves"), (17, "car: barrier 2"),
-        (18, "car: mask, column sums, df1 image"), (19, "car: per-lane sums"), (20, "car: barrier 3"), (5, "car: S accumulated (+ later rounds)"),
-        (30, "weights requested, S in LDS"), (31, "func.0 lane part (dd2, dA)"), (6, "weights in LDS again"), (32, "dec.2 bwd"),
+        (18, "car: mask, column sums, df1 image"), (19, "car: per-lane sums"), (20, "car: barrier 3"), (5, "car: S accumulated (earlier rounds)"),
+        (30, "operand requests, small sums parked, last round into S, S in LDS"), (31, "func.0 lane part (dA, dd2)"), (6, "barrier"), (32, "dec.2 bwd"),
         (33, "dec.0 bwd"), (34, "latent"), (35, "heads bwd"), (36, "rho.2 bwd"), (37, "rho.0 bwd"), (38, "phi.2 bwd"), (7, "phi.0 bwd"),
         (8, "slab, small sums, loc gradients")]
 
