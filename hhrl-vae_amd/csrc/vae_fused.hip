@@ -1735,6 +1735,24 @@ __device__ __forceinline__ float colsum16(const float* img, int ld, int col) {
 
 // SINGLE: the grid covers every tile (up to 256 tiles = 4096 traffic lanes): the tile loop runs once and no
 // gradient block has to live in a register across the car phase.
+// The same product with the B operand as 16-byte pieces of a weight row: lane (j, q) holds
+// b[t] = W[row j][16 t + 4 q .. 16 t + 4 q + 3], and step (t, e) of the product takes k = 16 t + 4 q + e from lane
+// group q (any one-to-one assignment of k to steps and groups gives the same sum).  A(i, k) = a[i * ASI + k].
+template <int K, int ASI>
+__device__ __forceinline__ f32x4 wave_mma16_bvec(const float* a, const float4 (&b)[K / 16], int lane, float init) {
+  static_assert(K % 16 == 0, "K must be a multiple of 16");
+  const float* ap = a + (lane & 15) * ASI + 4 * (lane >> 4);
+  f32x4 c0 = {init, init, init, init}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < K / 16; ++t) {
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * t], b[t].x, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * t + 1], b[t].y, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * t + 2], b[t].z, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16 * t + 3], b[t].w, c1, 0, 0, 0);
+  }
+  return c0 + c1;
+}
+
 template <bool SINGLE>
 __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1813,73 +1831,127 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
       if (i % 17 >= gd) ovl[LW_DEC0 + i] = 0.f;
   };
   // the tile's car states: 16 lanes x N x 2 floats (N <= STAGE_MAX_CARS), one float per thread
+  // (a float outside the tile or the batch is asked for at the batch's first float and replaced by zero when it is
+  //  stored: a conditional request would be joined with its alternative right here, and that join waits for the
+  //  value, i.e. for every request issued so far)
   auto request_cars16 = [&](int row0) -> float {
     const long base = (long)row0 * g.N * 2, lim = (long)g.B * g.N * 2;
     const int n = staged ? 2 * ST_ROWS * g.N : 0;
-    return (tid < n && base + tid < lim) ? g.data[base + tid] : 0.f;
+    return g.data[(tid < n && base + tid < lim) ? base + tid : 0];
   };
-  auto commit_cars16 = [&](float v) {
-    if (staged && tid < 2 * ST_ROWS * g.N) Icars[tid] = v;
+  auto commit_cars16 = [&](int row0, float v) {
+    const long base = (long)row0 * g.N * 2, lim = (long)g.B * g.N * 2;
+    if (staged && tid < 2 * ST_ROWS * g.N) Icars[tid] = base + tid < lim ? v : 0.f;
   };
 
-  // the position part of func.0, by the last 128 threads (output o each): p = E wloc, q = b0 + E bloc with
-  // E = W0[:, 32:].  Its loads go first, so that they have arrived when the rest of the requests has been issued.
+  // ---- requests of the prologue.  Before the first barrier only what the first phases read from LDS: phi.0's
+  // parameters, the biases, the small vectors of the per-car layers, the tile's cars, wloc and bloc.  Everything
+  // that stays in registers or is stored later follows: with one tile per workgroup right after the barrier, where
+  // it travels under phi.0 and the phases behind it (issued before the barrier, these ~45 requests per wave made
+  // the barrier wait for a memory pipeline that all 256 workgroups had just filled with the same requests).
   const int o_pq = tid - (NT - 128);
-  float4 pq_e[8], pq_w[8], pq_b[8];
-  float pq_b0 = 0.f;
-  if (o_pq >= 0) {
-    const float4* src = reinterpret_cast<const float4*>((g.params + g.ow[FUNC0]) + o_pq * 64 + 32);
-    const float4* wl4 = reinterpret_cast<const float4*>(g.params + g.ow[LOC]);
-    const float4* bl4 = reinterpret_cast<const float4*>(g.params + g.ob[LOC]);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      pq_e[e] = src[e];
-      pq_w[e] = wl4[e];
-      pq_b[e] = bl4[e];
-    }
-    pq_b0 = (g.params + g.ob[FUNC0])[o_pq];
-  }
+  const float loc_v = (g.params + ((tid & 32) ? g.ob[LOC] : g.ow[LOC]))[tid & 31];   // wloc | bloc, stored by threads 0..63
+  HHRL_STAMP(3, 44);
   const float phi0_v = tid < 32 ? (g.params + g.ow[PHI0])[tid] : (tid < 48 ? (g.params + g.ob[PHI0])[tid - 32] : 0.f);
   {
     const float* src = lane_bias_src_step(g, tid);
     rBias[0] = src ? *src : 0.f;
   }
-  request_weights(tid);
-  float4 v2[2];
-  request_w4<32, 128, 2, NT>(v2, (g.params + g.ow[FUNC2]), tid);
-  const float p_b2 = (g.params + g.ob[FUNC2])[r32], p_w4 = (g.params + g.ow[FUNC4])[r32], p_b4 = (g.params + g.ob[FUNC4])[0];
+  // (func.4's bias through a per-lane address: as a scalar load its arrival would be waited for by the next wait
+  //  on the scalar counter)
+  HHRL_STAMP(3, 45);
+  int lane_zero = 0;
+  asm volatile("" : "+v"(lane_zero));
+  const float p_b2 = (g.params + g.ob[FUNC2])[r32], p_w4 = (g.params + g.ow[FUNC4])[r32], p_b4 = (g.params + g.ob[FUNC4])[lane_zero];
   float car0 = request_cars16(blockIdx.x * ST_ROWS);
-  // func.0's columns for d2 (A = W0[:, :32]) as the B operand of U = d2 A^T: output column 16 wave + j,
-  // step s takes k = 4 s + q
+  HHRL_STAMP(3, 46);
+  // The position part of func.0, by the last 128 threads (output o each): p = E wloc, q = b0 + E bloc with
+  // E = W0[:, 32:].  The rows of E are kept in registers, wloc and bloc go through LDS (the slot of the backward's
+  // dd2 image, free until then), and the sums are formed under decoder.2, where these waves have nothing else to do.
+  float4 pq_e[8];
+  float pq_b0 = 0.f;
+  float4 v2[2];                                        // func.2's matrix, stored as an LDS image under decoder.2
+  // With one tile per workgroup every weight matrix of the lane layers is the B operand of one forward product
+  // (output block = 16 rows of the matrix, a lane holds 16-byte pieces of row j) and of one backward product, so
+  // the waves ask for their own operands and no image of these matrices is staged in LDS.  Forward: phi.2 on
+  // waves 0, 1; rho.0 and decoder.0 one block per wave; rho.2 on waves 0..3, decoder.2 on waves 4, 5 and the heads
+  // on waves 6, 7, which share one register array.
+  float4 fPhi2[1], fRho0[2], fBig[8];
+  float fDec0[4];
   float w0u[8];
-  {
+  // These requests are spread over the first phases (req_a before the first barrier, req_b .. req_e at the start of
+  // phi.0, phi.2, rho.0 and rho.2): a wave's 16-byte request occupies the CU's one path to the L1 for 16 clocks, the
+  // ~250 of them of a workgroup for 3-4 k clocks, and a barrier behind a burst of them waits for the burst.
+  auto req_a = [&]() {                                   // phi.2 and rho.0 operands
+    if (SINGLE) {
+      if (wave < 2) fPhi2[0] = *reinterpret_cast<const float4*>((g.params + g.ow[PHI2]) + (16 * wave + j) * 16 + 4 * q);
+      const float* src = (g.params + g.ow[RHO0]) + (16 * wave + j) * 32 + 4 * q;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) fRho0[t] = *reinterpret_cast<const float4*>(src + 16 * t);
+    }
+  };
+  auto req_b = [&]() {
+    if (SINGLE) {
+      // rows of rho.2 (waves 0..3), decoder.2 (waves 4, 5) or the heads (waves 6, 7: to_mean rows, then to_logvar
+      // rows; a block row beyond 2 g reads the first row, and its output column is set to zero)
+      const int hr = 16 * (wave - 6) + j;
+      const int at = wave < 4 ? g.ow[RHO2] + (16 * wave + j) * 128
+                   : wave < 6 ? g.ow[DEC2] + (16 * (wave - 4) + j) * 128
+                   : hr < gd ? g.ow[MEAN] + hr * 64 : g.ow[LOGVAR] + (hr < 2 * gd ? (hr - gd) * 64 : 0);
+      const float* src = g.params + at + 4 * q;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fBig[t] = *reinterpret_cast<const float4*>(src + 16 * t);
+      if (wave < 6) {
+#pragma unroll
+        for (int t = 4; t < 8; ++t) fBig[t] = *reinterpret_cast<const float4*>(src + 16 * t);
+      }
+    }
+  };
+  auto req_c = [&]() {
+    if (SINGLE) {
+      // decoder.0: W[row][k], k = 4 s + q < g; the other entries meet the zero columns of z
+      const float* src = (g.params + g.ow[DEC0]) + (16 * wave + j) * gd;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) fDec0[s] = src[4 * s + q < gd ? 4 * s + q : 0];
+    }
+    request_w4<32, 128, 2, NT>(v2, (g.params + g.ow[FUNC2]), tid);
+  };
+  auto req_d = [&]() {
+    // func.0's columns for d2 (A = W0[:, :32]) as the B operand of U = d2 A^T: output column 16 wave + j,
+    // step s takes k = 4 s + q
     const float* src = (g.params + g.ow[FUNC0]) + (16 * wave + j) * 64 + q;
 #pragma unroll
     for (int s = 0; s < 8; ++s) w0u[s] = src[4 * s];
-  }
-  if (o_pq >= 0) {
-    float pv = 0.f, qv = pq_b0;
+  };
+  auto req_e = [&]() {
+    if (o_pq >= 0) {
+      const float4* src = reinterpret_cast<const float4*>((g.params + g.ow[FUNC0]) + o_pq * 64 + 32);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      pv += pq_e[e].x * pq_w[e].x + pq_e[e].y * pq_w[e].y + pq_e[e].z * pq_w[e].z + pq_e[e].w * pq_w[e].w;
-      qv += pq_e[e].x * pq_b[e].x + pq_e[e].y * pq_b[e].y + pq_e[e].z * pq_b[e].z + pq_e[e].w * pq_b[e].w;
+      for (int e = 0; e < 8; ++e) pq_e[e] = src[e];
+      pq_b0 = (g.params + g.ob[FUNC0])[o_pq];
     }
-    bs[FB_Q + o_pq] = qv;
-    bs[FB_P + o_pq] = pv;
+  };
+  req_a();
+  if (!SINGLE) {
+    request_weights(tid);
+    req_b(); req_c(); req_d(); req_e();
   }
+  HHRL_STAMP(3, 40);
+  if (tid < 64) Itmp[tid] = loc_v;
   if (tid < 48) bs[FB_PHI0 + tid] = phi0_v;
   if (tid < LB_END) bs[tid] = rBias[0];
-  commit_weights(tid);
-  commit_w4<32, 128, 2, NT>(W2s, 129, v2, tid);
+  HHRL_STAMP(3, 41);
+  if (!SINGLE) commit_weights(tid);
   if (tid < 32) {
     b2s[tid] = p_b2;
     w4s[tid] = p_w4;
   }
   if (tid == 0) b4s[0] = p_b4;
   if (tid < ST_WAVES) b4s[8 + tid] = 0.f;               // first_lane[] of the car rounds
-  commit_cars16(car0);
-  if (blockIdx.x == 0 && tid < 64) g.aux[128 + tid] = tid < 32 ? (g.params + g.ow[LOC])[tid] : (g.params + g.ob[LOC])[tid - 32];
+  commit_cars16(blockIdx.x * ST_ROWS, car0);
+  HHRL_STAMP(3, 42);
   lds_barrier();
+  if (SINGLE) req_b();
   HHRL_STAMP(3, 1);
 
   // ---- what a workgroup keeps in registers across its tiles
@@ -2018,15 +2090,17 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
     const int ntiles = (ncars + CAR_TILE - 1) / CAR_TILE;
     if (!first) {                                      // the previous tile's images are dead (barrier at loop end)
       car0 = request_cars16(row0);
-      commit_cars16(car0);
+      commit_cars16(row0, car0);
       lds_barrier();
     }
     // the tile's reparameterisation noise: one element of [16][32] per thread (column c: mean part c < g, logvar part)
-    float eps_t = 0.f;
+    // (threads without an element ask for the batch's first one and never use it: a conditional request would be
+    //  joined with its alternative here, and the join waits for every request in flight)
+    float eps_t;
     {
       const int rr = tid >> 5, c = tid & 31;
       const int jj = c < gd ? c : c - gd;
-      if (c < 2 * gd && row0 + rr < g.B) eps_t = g.eps[(long)(row0 + rr) * gd + jj];
+      eps_t = g.eps[(c < 2 * gd && row0 + rr < g.B) ? (long)(row0 + rr) * gd + jj : 0];
     }
     HHRL_STAMP(3, 2);
     // ================================================================= per-lane forward
@@ -2050,30 +2124,45 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
     lds_barrier();
     HHRL_STAMP(3, 22);
     // ---- phi.2 on the summed hidden: pooled = W2 h1s + N b2 (two blocks)
+    if (SINGLE) req_c();
     if (wave < 2) {
-      const f32x4 c = wave_mma16<16, 33, 1, 1, 17>(Ih1, ovl + LW_PHI2 + 16 * wave * 17, lane, (float)g.N * bs[LB_PHI2 + 16 * wave + j]);
+      const float b0v = (float)g.N * bs[LB_PHI2 + 16 * wave + j];
+      const f32x4 c = SINGLE ? wave_mma16_bvec<16, 33>(Ih1, fPhi2, lane, b0v)
+                             : wave_mma16<16, 33, 1, 1, 17>(Ih1, ovl + LW_PHI2 + 16 * wave * 17, lane, b0v);
       store_block16<33>(Ipool, 0, 16 * wave, c, lane);
     }
     lds_barrier();
     HHRL_STAMP(3, 23);
     // ---- rho.0 (32 -> 128, ReLU): block `wave`
+    if (SINGLE) req_d();
     {
-      f32x4 c = wave_mma16<32, 33, 1, 1, 33>(Ipool, ovl + LW_RHO0 + 16 * wave * 33, lane, bs[LB_RHO0 + 16 * wave + j]);
+      f32x4 c = SINGLE ? wave_mma16_bvec<32, 33>(Ipool, fRho0, lane, bs[LB_RHO0 + 16 * wave + j])
+                       : wave_mma16<32, 33, 1, 1, 33>(Ipool, ovl + LW_RHO0 + 16 * wave * 33, lane, bs[LB_RHO0 + 16 * wave + j]);
 #pragma unroll
       for (int e = 0; e < 4; ++e) c[e] = fmaxf(c[e], 0.f);
       store_block16<129>(Ir1, 0, 16 * wave, c, lane);
     }
     lds_barrier();
     HHRL_STAMP(3, 24);
-    // ---- rho.2 (128 -> 64): four blocks on waves 0..3; meanwhile the last 128 threads form p and q (first tile)
+    // ---- rho.2 (128 -> 64): four blocks on waves 0..3
+    if (SINGLE) req_e();
     if (wave < 4) {
-      const f32x4 c = wave_mma16<128, 129, 1, 1, 129>(Ir1, ovl + LW_RHO2 + 16 * wave * 129, lane, bs[LB_RHO2 + 16 * wave + j]);
+      const f32x4 c = SINGLE ? wave_mma16_bvec<128, 129>(Ir1, fBig, lane, bs[LB_RHO2 + 16 * wave + j])
+                             : wave_mma16<128, 129, 1, 1, 129>(Ir1, ovl + LW_RHO2 + 16 * wave * 129, lane, bs[LB_RHO2 + 16 * wave + j]);
       store_block16<65>(Ir2, 0, 16 * wave, c, lane);
     }
     lds_barrier();
     HHRL_STAMP(3, 25);
     // ---- heads (64 -> 2g; columns >= 2g come out as zero): two blocks
-    if (wave < 2) {
+    if (SINGLE) {
+      if (wave >= 6) {
+        const int hb = wave - 6;
+        const float4 (&fHead)[4] = reinterpret_cast<const float4 (&)[4]>(fBig);
+        f32x4 c = wave_mma16_bvec<64, 65>(Ir2, fHead, lane, bs[LB_HEAD + 16 * hb + j]);
+        if (16 * hb + j >= 2 * gd) c = zero4;
+        store_block16<33>(Iml, 0, 16 * hb, c, lane);
+      }
+    } else if (wave < 2) {
       const f32x4 c = wave_mma16<64, 65, 1, 1, 65>(Ir2, ovl + LW_HEAD + 16 * wave * 65, lane, bs[LB_HEAD + 16 * wave + j]);
       store_block16<33>(Iml, 0, 16 * wave, c, lane);
     }
@@ -2092,7 +2181,8 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
     HHRL_STAMP(3, 27);
     // ---- decoder.0 (g -> 128, ReLU): block `wave`
     {
-      f32x4 c = wave_mma16<16, 17, 1, 1, 17>(Iz, ovl + LW_DEC0 + 16 * wave * 17, lane, bs[LB_DEC0 + 16 * wave + j]);
+      f32x4 c = SINGLE ? wave_mma16_breg<16, 17, 1>(Iz, fDec0, lane, bs[LB_DEC0 + 16 * wave + j])
+                       : wave_mma16<16, 17, 1, 1, 17>(Iz, ovl + LW_DEC0 + 16 * wave * 17, lane, bs[LB_DEC0 + 16 * wave + j]);
 #pragma unroll
       for (int e = 0; e < 4; ++e) c[e] = fmaxf(c[e], 0.f);
       store_block16<129>(Id1, 0, 16 * wave, c, lane);
@@ -2100,9 +2190,31 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
     lds_barrier();
     HHRL_STAMP(3, 28);
     // ---- decoder.2 (128 -> 32): two blocks
-    if (wave < 2) {
+    if (SINGLE) {
+      if (wave == 4 || wave == 5) {
+        const int db = wave - 4;
+        const f32x4 c = wave_mma16_bvec<128, 129>(Id1, fBig, lane, bs[LB_DEC2 + 16 * db + j]);
+        store_block16<33>(Id2, 0, 16 * db, c, lane);
+      }
+    } else if (wave < 2) {
       const f32x4 c = wave_mma16<128, 129, 1, 1, 129>(Id1, ovl + LW_DEC2 + 16 * wave * 129, lane, bs[LB_DEC2 + 16 * wave + j]);
       store_block16<33>(Id2, 0, 16 * wave, c, lane);
+    }
+    if (first) {
+      // what the prologue's later requests brought and the phases from here on read from LDS: func.2's image, p and q
+      commit_w4<32, 128, 2, NT>(W2s, 129, v2, tid);
+      if (o_pq >= 0) {
+        float pv = 0.f, qv = pq_b0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float* wl = Itmp + 4 * e;
+          const float* bl = Itmp + 32 + 4 * e;
+          pv += pq_e[e].x * wl[0] + pq_e[e].y * wl[1] + pq_e[e].z * wl[2] + pq_e[e].w * wl[3];
+          qv += pq_e[e].x * bl[0] + pq_e[e].y * bl[1] + pq_e[e].z * bl[2] + pq_e[e].w * bl[3];
+        }
+        bs[FB_Q + o_pq] = qv;
+        bs[FB_P + o_pq] = pv;
+      }
     }
     lds_barrier();
     HHRL_STAMP(3, 3);
@@ -2556,6 +2668,9 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) w0x[k] = (g.params + g.ow[FUNC0])[(8 * og + k) * 64 + 32 + jj];
   }
+  // the loc embedding as it is before this step's update, for the slab sum: every thread asks (no branch around
+  // the request), workgroup 0 stores at the very end
+  const float loc_copy = (g.params + ((tid & 32) ? g.ob[LOC] : g.ow[LOC]))[tid & 31];
   if (!SINGLE) {
     write_f0();
     write_dec2();
@@ -2621,6 +2736,7 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
 #pragma unroll
     for (int og = 0; og < 16; og += 4) sum += (pp[og * 64] + pp[(og + 1) * 64]) + (pp[(og + 2) * 64] + pp[(og + 3) * 64]);
     slab[(tid < 32 ? g.ow[LOC] + tid : g.ob[LOC] + tid - 32)] = sum;
+    if (blockIdx.x == 0) g.aux[128 + tid] = loc_copy;
   }
   HHRL_STAMP(3, 8);
   HHRL_WG_SPAN(1);

@@ -31,7 +31,9 @@ LBWD = ["start", "weights, activations, S in LDS", "func.0 lane part (dd2, dA)",
 
 
 # the one-launch step: (stamp number, what ended there), in the order the kernel passes them
-STEP = [(0, "start"), (1, "weights, W2, cars in LDS"), (2, "tile start"), (22, "phi.0"), (23, "phi.2"), (24, "rho.0"), (25, "rho.2"),
+STEP = [(0, "start"), (44, "prologue: kernel arguments, p/q requests (waves 6, 7)"), (45, "prologue: phi.0, biases, func.2 requested"),
+        (46, "prologue: cars requested"), (40, "prologue: operands requested"), (41, "prologue: biases arrived and stored"), (42, "prologue: W2, cars stored"),
+        (1, "prologue: barrier"), (2, "tile start"), (22, "phi.0"), (23, "phi.2"), (24, "rho.0"), (25, "rho.2"),
         (26, "heads"), (27, "reparam"), (28, "dec.0"), (3, "dec.2"), (4, "U = d2 A^T + q"),
         (10, "car: inputs, func.0"), (11, "car: func.2 fwd"), (12, "car: func.4 + err"), (13, "car: func.4 bwd"),
         (14, "car: df2 W2"), (15, "car: barrier 1"), (16, "car: dW2 across waves"), (17, "car: barrier 2"),
