@@ -1879,9 +1879,11 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
   float4 fPhi2[1], fRho0[2], fBig[8];
   float fDec0[4];
   float w0u[8];
-  // These requests are spread over the first phases (req_a before the first barrier, req_b .. req_e at the start of
-  // phi.0, phi.2, rho.0 and rho.2): a wave's 16-byte request occupies the CU's one path to the L1 for 16 clocks, the
-  // ~250 of them of a workgroup for 3-4 k clocks, and a barrier behind a burst of them waits for the burst.
+  // These requests are spread over the first phases (req_a before the first barrier, req_b right after it, req_c
+  // behind phi.2's product, req_d and req_e behind rho.2's): a wave's 16-byte request occupies the CU's one path to
+  // the L1 for 16 clocks, the ~250 of them of a workgroup for 3-4 k clocks, and a barrier behind a burst of them
+  // waits for the burst.  They are issued by all waves alike where that is possible: a request that only some waves
+  // issue makes every later wait count as if none had.
   auto req_a = [&]() {                                   // phi.2 and rho.0 operands
     if (SINGLE) {
       if (wave < 2) fPhi2[0] = *reinterpret_cast<const float4*>((g.params + g.ow[PHI2]) + (16 * wave + j) * 16 + 4 * q);
@@ -2124,17 +2126,16 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
     lds_barrier();
     HHRL_STAMP(3, 22);
     // ---- phi.2 on the summed hidden: pooled = W2 h1s + N b2 (two blocks)
-    if (SINGLE) req_c();
     if (wave < 2) {
       const float b0v = (float)g.N * bs[LB_PHI2 + 16 * wave + j];
       const f32x4 c = SINGLE ? wave_mma16_bvec<16, 33>(Ih1, fPhi2, lane, b0v)
                              : wave_mma16<16, 33, 1, 1, 17>(Ih1, ovl + LW_PHI2 + 16 * wave * 17, lane, b0v);
       store_block16<33>(Ipool, 0, 16 * wave, c, lane);
     }
+    if (SINGLE) req_c();
     lds_barrier();
     HHRL_STAMP(3, 23);
     // ---- rho.0 (32 -> 128, ReLU): block `wave`
-    if (SINGLE) req_d();
     {
       f32x4 c = SINGLE ? wave_mma16_bvec<32, 33>(Ipool, fRho0, lane, bs[LB_RHO0 + 16 * wave + j])
                        : wave_mma16<32, 33, 1, 1, 33>(Ipool, ovl + LW_RHO0 + 16 * wave * 33, lane, bs[LB_RHO0 + 16 * wave + j]);
@@ -2145,11 +2146,14 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
     lds_barrier();
     HHRL_STAMP(3, 24);
     // ---- rho.2 (128 -> 64): four blocks on waves 0..3
-    if (SINGLE) req_e();
     if (wave < 4) {
       const f32x4 c = SINGLE ? wave_mma16_bvec<128, 129>(Ir1, fBig, lane, bs[LB_RHO2 + 16 * wave + j])
                              : wave_mma16<128, 129, 1, 1, 129>(Ir1, ovl + LW_RHO2 + 16 * wave * 129, lane, bs[LB_RHO2 + 16 * wave + j]);
       store_block16<65>(Ir2, 0, 16 * wave, c, lane);
+    }
+    if (SINGLE) {
+      req_d();
+      req_e();
     }
     lds_barrier();
     HHRL_STAMP(3, 25);
