@@ -153,7 +153,8 @@ __device__ __forceinline__ void load_w_bwd(WBwd& W, const Net& g, int wave, int 
 struct TileIn {
   float x[ROWS * KMAX / NT];      // 2
   float4 h1, h2;                  // backward only
-  float d3;                       // backward only
+  float d3, y3;                   // backward only: dL/dy and the output y, combined by commit_bwd
+  bool okd;
 };
 __device__ __forceinline__ void request_x(TileIn& T, const Net& g, int row0, int M, int tid, int K0p) {
 #pragma unroll
@@ -174,20 +175,29 @@ __device__ __forceinline__ void request_bwd(TileIn& T, const Net& g, int row0, i
   const bool ok = row0 + rr < M;
   T.h1 = ok ? *reinterpret_cast<const float4*>(g.h1 + (long)(row0 + rr) * H + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
   T.h2 = ok ? *reinterpret_cast<const float4*>(g.h2 + (long)(row0 + rr) * H + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  // dL/dy and the output it is scaled by are only asked for here and combined when they are stored: combined here,
+  // the values would be waited for before the requests that follow (the tile's inputs, the weights) are issued.
+  // Threads without an element, and the case without a dy / without an output activation, ask for a word that
+  // exists (the first of h1) and do not use it: no branch around a request, and no generic-address load.
   const int dr = tid / N3p, dc = tid - dr * N3p;
-  float v = 0.f;
-  if (dr < ROWS && dc < g.N3 && row0 + dr < M) {
-    v = g.dy ? g.dy[(long)(row0 + dr) * g.lddy + dc] : g.dy_const;
-    if (g.act3 != HHRL_ACT_NONE) v *= act_grad_from_output(g.y[(long)(row0 + dr) * g.ldy + dc], g.act3);
-  }
-  T.d3 = v;
+  const bool okd = dr < ROWS && dc < g.N3 && row0 + dr < M;
+  const float* dyp = g.dy ? g.dy : g.h1;
+  const float* yp = g.act3 != HHRL_ACT_NONE ? g.y : g.h1;
+  T.d3 = dyp[okd && g.dy ? (long)(row0 + dr) * g.lddy + dc : 0];
+  T.y3 = yp[okd && g.act3 != HHRL_ACT_NONE ? (long)(row0 + dr) * g.ldy + dc : 0];
+  T.okd = okd;
 }
-__device__ __forceinline__ void commit_bwd(float* lds, const TileIn& T, int tid, int N3p) {
+__device__ __forceinline__ void commit_bwd(float* lds, const TileIn& T, const Net& g, int tid, int N3p) {
   const int rr = tid >> 5, c4 = (tid & 31) * 4;
   *reinterpret_cast<float4*>(lds + L_A1 + rr * LDA + c4) = T.h1;
   *reinterpret_cast<float4*>(lds + L_A2 + rr * LDA + c4) = T.h2;
   const int dr = tid / N3p, dc = tid - dr * N3p;
-  if (dr < ROWS) lds[L_D3 + dr * LDD + dc] = T.d3;
+  float v = 0.f;
+  if (T.okd) {
+    v = g.dy ? T.d3 : g.dy_const;
+    if (g.act3 != HHRL_ACT_NONE) v *= act_grad_from_output(T.y3, g.act3);
+  }
+  if (dr < ROWS) lds[L_D3 + dr * LDD + dc] = v;
 }
 
 // Sum of the eight waves' partial blocks, in wave order: out(row, col) for col < 16 * nb
@@ -446,7 +456,7 @@ __global__ __launch_bounds__(NT, 1) void mlp3_backward_kernel(NetGroup grp, int 
   G.b1 = G.b2 = G.b3 = 0.f;
   for (; tile < tiles; tile += gridDim.x) {
     commit_x(lds, T, tid, K0p);
-    commit_bwd(lds, T, tid, N3p);
+    commit_bwd(lds, T, g, tid, N3p);
     lds_barrier();
     MLP_STAMP(1, sn++);
     if (tile + (int)gridDim.x < tiles) {
