@@ -48,7 +48,7 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 // Stores for results that a LATER kernel reads (gradient slabs, activations handed on): written through the L2
-// (agent scope; the 16-byte form as a streaming store) as they are produced.  Left as ordinary stores they stay
+// (agent scope) as they are produced.  Left as ordinary stores they stay
 // dirty in the L2 until the kernel ends, and the end of the kernel waits for their write-back: 25 MB of slabs add
 // 2.6 us to a 36 us kernel.  -DHHRL_PLAIN_STORES builds the ordinary stores for comparison.
 __device__ __forceinline__ void store_through(float* p, float v) {
@@ -62,9 +62,13 @@ __device__ __forceinline__ void store_through(float4* p, const float4& v) {
 #ifdef HHRL_PLAIN_STORES
   *p = v;
 #else
+  // the 16-byte form of the agent-scope store above (the compiler offers it for 4 bytes only); a streaming store
+  // (nt) leaves the kernel as early, but the kernel that reads the data next then takes longer to get it
   typedef float v4f __attribute__((ext_vector_type(4)));
   const v4f t = {v.x, v.y, v.z, v.w};
-  __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
+  // (s_nop: a store of more than 8 bytes reads its data registers up to two cycles after it issues, and inside an
+  //  asm statement the compiler does not keep the next instruction from overwriting them)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(t) : "memory");
 #endif
 }
 

@@ -1985,14 +1985,20 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
       if (row < row_lim && col < col_lim) slab_put(&slab[base + (long)row * ld + col], t[e]);
     }
   };
+  // The weight-gradient products below are formed with their operands in each other's place: a lane then holds four
+  // consecutive columns of one row of dW (row row0 + j, columns col0 + 4 q ..) and hands them over with one 16-byte
+  // store, a quarter of the store instructions of the row-per-register layout.
+  auto put16t = [&](long base, int ld, int row0, int col0, const f32x4& t) {
+    store_through(reinterpret_cast<float4*>(&slab[base + (long)(row0 + j) * ld + col0 + 4 * q]), make_float4(t[0], t[1], t[2], t[3]));
+  };
   const int bt = tid - 256;                            // owner index of the bias-gradient column sums
   auto write_f0 = [&]() {
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) put16(g.ow[FUNC0], 64, 16 * wave, 128, 16 * cb, 32, aF0[cb]);
+    for (int cb = 0; cb < 2; ++cb) put16t(g.ow[FUNC0], 64, 16 * wave, 16 * cb, aF0[cb]);
   };
   auto write_dec2 = [&]() {
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) put16(g.ow[DEC2], 128, 16 * rb, 32, 16 * wave, 128, aDec2[rb]);
+    for (int rb = 0; rb < 2; ++rb) put16t(g.ow[DEC2], 128, 16 * rb, 16 * wave, aDec2[rb]);
     if (bt >= 0 && bt < 32) slab_put(&slab[g.ob[DEC2] + bt], bDec2);
   };
   auto write_dec0 = [&]() {
@@ -2001,28 +2007,25 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
   };
   auto write_heads = [&]() {
     // rows < g belong to to_mean, rows g..2g-1 to to_logvar
-    const int col = 16 * (wave & 3) + j;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int row = 16 * (wave >> 2) + 4 * q + e;
-      if (row < gd) slab_put(&slab[g.ow[MEAN] + (long)row * 64 + col], aHead[e]);
-      else if (row < 2 * gd) slab_put(&slab[g.ow[LOGVAR] + (long)(row - gd) * 64 + col], aHead[e]);
-    }
+    const int row = 16 * (wave >> 2) + j, col = 16 * (wave & 3) + 4 * q;
+    const float4 t = make_float4(aHead[0], aHead[1], aHead[2], aHead[3]);
+    if (row < gd) store_through(reinterpret_cast<float4*>(&slab[g.ow[MEAN] + (long)row * 64 + col]), t);
+    else if (row < 2 * gd) store_through(reinterpret_cast<float4*>(&slab[g.ow[LOGVAR] + (long)(row - gd) * 64 + col]), t);
     if (bt >= 0 && bt < gd) slab_put(&slab[g.ob[MEAN] + bt], bHead);
     else if (bt >= 0 && bt < 2 * gd) slab_put(&slab[g.ob[LOGVAR] + bt - gd], bHead);
   };
   auto write_rho2 = [&]() {
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) put16(g.ow[RHO2], 128, 16 * rb, 64, 16 * wave, 128, aRho2[rb]);
+    for (int rb = 0; rb < 4; ++rb) put16t(g.ow[RHO2], 128, 16 * rb, 16 * wave, aRho2[rb]);
     if (bt >= 0 && bt < 64) slab_put(&slab[g.ob[RHO2] + bt], bRho2);
   };
   auto write_rho0 = [&]() {
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) put16(g.ow[RHO0], 32, 16 * wave, 128, 16 * cb, 32, aRho0[cb]);
+    for (int cb = 0; cb < 2; ++cb) put16t(g.ow[RHO0], 32, 16 * wave, 16 * cb, aRho0[cb]);
     if (bt >= 0 && bt < 128) slab_put(&slab[g.ob[RHO0] + bt], bRho0);
   };
   auto write_phi2 = [&]() {
-    if (wave < 2) put16(g.ow[PHI2], 16, 16 * wave, 32, 0, 16, aPhi2);
+    if (wave < 2) put16t(g.ow[PHI2], 16, 16 * wave, 0, aPhi2);
     if (bt >= 0 && bt < 32) slab_put(&slab[g.ob[PHI2] + bt], bPhi2);
   };
   auto write_phi0 = [&]() {
@@ -2032,7 +2035,7 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
   };
   auto write_func2 = [&]() {
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) put16(g.ow[FUNC2], 128, 16 * rb, 32, 16 * wave, 128, dW2a[rb]);
+    for (int rb = 0; rb < 2; ++rb) put16t(g.ow[FUNC2], 128, 16 * rb, 16 * wave, dW2a[rb]);
   };
 
   // The waves' small sums meet in LDS, Q1 floats per wave: db0[128] s[128] db2[32] w4[32] b4 loss kl.  With one tile
@@ -2377,8 +2380,8 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const float bv = b0[4 * s * 129];
-          dW2a[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[4 * s * 33], bv, dW2a[0], 0, 0, 0);
-          dW2a[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[4 * s * 33 + 16], bv, dW2a[1], 0, 0, 0);
+          dW2a[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, a0[4 * s * 33], dW2a[0], 0, 0, 0);
+          dW2a[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, a0[4 * s * 33 + 16], dW2a[1], 0, 0, 0);
         }
       }
       HHRL_STAMP(3, 16);
@@ -2484,7 +2487,7 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
     // ---- func.0, the part shared by a lane's cars: dd2 = S A (waves 0, 1), dA[128][32] += S^T d2 (row block `wave`)
     {
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) aF0[cb] = wave_mma16<16, 1, 129, 33, 1>(Iu + 16 * wave, Id2 + 16 * cb, lane, aF0[cb]);
+      for (int cb = 0; cb < 2; ++cb) aF0[cb] = wave_mma16<16, 1, 33, 129, 1>(Id2 + 16 * cb, Iu + 16 * wave, lane, aF0[cb]);
       if (SINGLE) write_f0();
       if (wave < 2) {
         const float* ap = Iu + j * 129 + q;
@@ -2507,7 +2510,7 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
     // ---- decoder.2 backward: dW[32][128] += dd2^T d1 (column block `wave`), db, dd1 = (dd2 W) o relu'(d1) in place
     {
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) aDec2[rb] = wave_mma16<16, 1, 33, 129, 1>(Itmp + 16 * rb, Id1 + 16 * wave, lane, aDec2[rb]);
+      for (int rb = 0; rb < 2; ++rb) aDec2[rb] = wave_mma16<16, 1, 129, 33, 1>(Id1 + 16 * wave, Itmp + 16 * rb, lane, aDec2[rb]);
       if (SINGLE) {
         const float* s = (g.params + g.ow[RHO2]) + q * 128 + 16 * wave + j;
 #pragma unroll
@@ -2562,7 +2565,7 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
     HHRL_STAMP(3, 34);
     // ---- heads backward: dW[2g][64] += dml^T r2 (block (wave / 4, wave % 4)), db, dr2 = dml W (waves 0..3; replaces r2)
     {
-      aHead = wave_mma16<16, 1, 33, 65, 1>(Idml + 16 * (wave >> 2), Ir2 + 16 * (wave & 3), lane, aHead);
+      aHead = wave_mma16<16, 1, 65, 33, 1>(Ir2 + 16 * (wave & 3), Idml + 16 * (wave >> 2), lane, aHead);
       f32x4 d = zero4;
       if (wave < 4)
         d = SINGLE ? wave_mma16_breg<32, 33, 1>(Idml, bHeadr, lane, 0.f)
@@ -2577,7 +2580,7 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
     // ---- rho.2 backward: dW[64][128] += dr2^T r1 (column block `wave`, four row blocks), db, dr1 = (dr2 W) o relu'(r1) in place
     {
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) aRho2[rb] = wave_mma16<16, 1, 65, 129, 1>(Ir2 + 16 * rb, Ir1 + 16 * wave, lane, aRho2[rb]);
+      for (int rb = 0; rb < 4; ++rb) aRho2[rb] = wave_mma16<16, 1, 129, 65, 1>(Ir1 + 16 * wave, Ir2 + 16 * rb, lane, aRho2[rb]);
       if (SINGLE && wave < 2) {
         const float* s = (g.params + g.ow[RHO0]) + q * 32 + 16 * wave + j;
 #pragma unroll
@@ -2604,7 +2607,7 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
     // ---- rho.0 backward: dW[128][32] += dr1^T pooled (row block `wave`), db, dpooled = dr1 W (waves 0, 1) -> ml slot
     {
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) aRho0[cb] = wave_mma16<16, 1, 129, 33, 1>(Ir1 + 16 * wave, Ipool + 16 * cb, lane, aRho0[cb]);
+      for (int cb = 0; cb < 2; ++cb) aRho0[cb] = wave_mma16<16, 1, 33, 129, 1>(Ipool + 16 * cb, Ir1 + 16 * wave, lane, aRho0[cb]);
       if (wave < 2) {
         const f32x4 c = SINGLE ? wave_mma16_breg<128, 129, 1>(Ir1, bRho0r, lane, 0.f)
                                : wave_mma16<128, 129, 1, 33, 1>(Ir1, ovl + LW_RHO0 + 16 * wave, lane, 0.f);
@@ -2619,7 +2622,7 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
     //      t = dpooled W_phi2 (wave 2): gradient at the hidden layer of every car of the lane, before its ReLU mask
     {
       if (wave < 2) {
-        aPhi2 = wave_mma16<16, 1, 33, 33, 1>(Iml + 16 * wave, Ih1, lane, aPhi2);
+        aPhi2 = wave_mma16<16, 1, 33, 33, 1>(Ih1, Iml + 16 * wave, lane, aPhi2);
       } else if (wave == 2) {
         const f32x4 c = SINGLE ? wave_mma16_breg<32, 33, 1>(Iml, bPhi2r, lane, 0.f)
                                : wave_mma16<32, 33, 1, 17, 1>(Iml, ovl + LW_PHI2, lane, 0.f);
