@@ -370,49 +370,41 @@ __device__ __forceinline__ void gemm_tiny_body(const GemmArgs& g, int bx, int by
   const bool masked = g.Y != nullptr;
   const bool want_rs = g.rowsum != nullptr && bx == 0;
   float rs = 0.f;
+  // Requests carry no conditions: an element beyond the chunk's k range is asked for at the chunk's last valid k and
+  // replaced by zero when the chunk is written to LDS.  (A conditional request is joined with its alternative where
+  // it is issued, and that join waits for every request in flight: the chunk's requests then cost one memory round
+  // trip each instead of one together.  The 32 x 32 kernel above keeps its conditional, pointer-stepping requests:
+  // both unconditional forms tried there were slower, its joins fall where the values are needed anyway.)
   float av[8], bv[8], mv[8];
   auto request = [&](int k0) {
-    const int kc = min(SKC, kend - k0);
+    const int kc = min(SKC, kend - k0);                  // >= 1
+    // element t of this lane: (row, k) of A and of the mask Y
+    long arow[8];
+    int ak[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      av[t] = 0.f;
-      bv[t] = 0.f;
-      mv[t] = 0.f;
+      arow[t] = g.a_kcontig ? i0 + min(8 * hf + t, nra - 1) : i0 + min(rr, nra - 1);
+      ak[t] = k0 + (g.a_kcontig ? min(kl, kc - 1) : min(kq + 4 * t, kc - 1));
     }
-    if (g.a_kcontig) {
-      if (kl < kc) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const long row = i0 + min(8 * hf + t, nra - 1);
-          av[t] = g.A[row * g.a_si + (k0 + kl)];
-          if (masked) mv[t] = g.Y[row * g.y_si + (long)(k0 + kl) * g.y_sk];
-        }
-      }
-    } else {
-      const long row = i0 + min(rr, nra - 1);
+    for (int t = 0; t < 8; ++t) av[t] = g.A[arow[t] * g.a_si + (long)ak[t] * g.a_sk];
+    if (masked) {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int k = kq + 4 * t;
-        if (k < kc) {
-          av[t] = g.A[row * g.a_si + (long)(k0 + k) * g.a_sk];
-          if (masked) mv[t] = g.Y[row * g.y_si + (long)(k0 + k) * g.y_sk];
-        }
-      }
+      for (int t = 0; t < 8; ++t) mv[t] = g.Y[arow[t] * g.y_si + (long)ak[t] * g.y_sk];
     }
     if (g.b_kcontig) {
-      if (kl < kc) {
+      const int kk = k0 + min(kl, kc - 1);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const long col = j0 + min(8 * hf + t, ncb - 1);
-          bv[t] = g.B[col * g.b_sj + (k0 + kl)];
-        }
+      for (int t = 0; t < 8; ++t) {
+        const long col = j0 + min(8 * hf + t, ncb - 1);
+        bv[t] = g.B[col * g.b_sj + kk];
       }
     } else {
       const long col = j0 + min(rr, ncb - 1);
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        const int k = kq + 4 * t;
-        if (k < kc) bv[t] = g.B[(long)(k0 + k) * g.b_sk + col * g.b_sj];
+        const int k = k0 + min(kq + 4 * t, kc - 1);
+        bv[t] = g.B[(long)k * g.b_sk + col * g.b_sj];
       }
     }
   };
@@ -436,18 +428,20 @@ __device__ __forceinline__ void gemm_tiny_body(const GemmArgs& g, int bx, int by
     }
     // every row of both images is written for every chunk (zeros beyond the chunk's k range)
     if (g.a_kcontig) {
+      const bool in = kl < kc;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) As[kl][8 * hf + t] = av[t];
+      for (int t = 0; t < 8; ++t) As[kl][8 * hf + t] = in ? av[t] : 0.f;
     } else {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) As[kq + 4 * t][rr] = av[t];
+      for (int t = 0; t < 8; ++t) As[kq + 4 * t][rr] = kq + 4 * t < kc ? av[t] : 0.f;
     }
     if (g.b_kcontig) {
+      const bool in = kl < kc;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) Bs[kl][8 * hf + t] = bv[t];
+      for (int t = 0; t < 8; ++t) Bs[kl][8 * hf + t] = in ? bv[t] : 0.f;
     } else {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) Bs[kq + 4 * t][rr] = bv[t];
+      for (int t = 0; t < 8; ++t) Bs[kq + 4 * t][rr] = kq + 4 * t < kc ? bv[t] : 0.f;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
