@@ -2014,10 +2014,18 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
     if (bt >= 0 && bt < gd) slab_put(&slab[g.ob[MEAN] + bt], bHead);
     else if (bt >= 0 && bt < 2 * gd) slab_put(&slab[g.ob[LOGVAR] + bt - gd], bHead);
   };
-  auto write_rho2 = [&]() {
+  auto write_rho2_lo = [&]() {
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) put16t(g.ow[RHO2], 128, 16 * rb, 16 * wave, aRho2[rb]);
+    for (int rb = 0; rb < 2; ++rb) put16t(g.ow[RHO2], 128, 16 * rb, 16 * wave, aRho2[rb]);
     if (bt >= 0 && bt < 64) slab_put(&slab[g.ob[RHO2] + bt], bRho2);
+  };
+  auto write_rho2_hi = [&]() {
+#pragma unroll
+    for (int rb = 2; rb < 4; ++rb) put16t(g.ow[RHO2], 128, 16 * rb, 16 * wave, aRho2[rb]);
+  };
+  auto write_rho2 = [&]() {
+    write_rho2_lo();
+    write_rho2_hi();
   };
   auto write_rho0 = [&]() {
 #pragma unroll
@@ -2601,7 +2609,11 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
       }
       if (tid >= 256 && tid < 320) bRho2 += colsum16(Ir2, 65, tid - 256);
     }
-    if (SINGLE) write_rho2();
+    // (the slab entries of the last layers leave in portions of about 16 KB per phase, one phase behind their
+    //  products where needed: a CU hands about 21 bytes per clock to memory through agent-scope stores
+    //  (tools/probes/write_through_probe.hip), its queue takes about that much without holding the storing waves
+    //  up, and rho.2's 32 KB in one go held them 2.6 k clocks)
+    if (SINGLE) write_rho2_lo();
     lds_barrier();
     HHRL_STAMP(3, 36);
     // ---- rho.0 backward: dW[128][32] += dr1^T pooled (row block `wave`), db, dpooled = dr1 W (waves 0, 1) -> ml slot
@@ -2615,7 +2627,7 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
       }
       if (tid >= 256 && tid < 384) bRho0 += colsum16(Ir1, 129, tid - 256);
     }
-    if (SINGLE) write_rho0();
+    if (SINGLE) write_rho2_hi();
     lds_barrier();
     HHRL_STAMP(3, 37);
     // ---- phi.2 backward on the summed hidden: dW[32][16] += dpooled^T h1s (waves 0, 1), db = N colsum(dpooled),
@@ -2630,7 +2642,7 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
       }
       if (tid >= 256 && tid < 288) bPhi2 += (float)g.N * colsum16(Iml, 33, tid - 256);
     }
-    if (SINGLE) write_phi2();
+    if (SINGLE) write_rho0();
     lds_barrier();
     HHRL_STAMP(3, 38);
     // ---- phi.0 backward: per (lane, hidden unit) walk the cars again and apply the ReLU mask
@@ -2662,7 +2674,10 @@ __global__ __launch_bounds__(ST_NT, 1) void vae_step_kernel(StepArgs g) {
         gPhi0 += s;
       }
     }
-    if (SINGLE) write_phi0();
+    if (SINGLE) {
+      write_phi2();
+      write_phi0();
+    }
     lds_barrier();
     HHRL_STAMP(3, 7);
   } while (!SINGLE && (tile += gridDim.x) < g.tiles);
