@@ -19,7 +19,7 @@ _L = C.c_long
 _F = C.c_float
 _D = C.c_double
 
-ABI_VERSION = 101            # HHRL_ABI_VERSION of include/hhrl_hip.h
+ABI_VERSION = 102            # HHRL_ABI_VERSION of include/hhrl_hip.h
 
 
 class LstmDesc(C.Structure):
@@ -54,6 +54,12 @@ class Mlp3Desc(C.Structure):
 MLP3_GROUP_MAX = 8
 
 
+class AdamRide(C.Structure):
+    """hhrl_adam_ride of include/hhrl_hip.h."""
+    _fields_ = [("grads", _P), ("params", _P), ("m", _P), ("v", _P), ("n", _L), ("hyper_dev", _P),
+                ("target", _P), ("tau", C.c_double)]
+
+
 class GCopyDesc(C.Structure):
     """hhrl_gcopy_desc of include/hhrl_hip.h."""
     _fields_ = [("inp", _P), ("ldi", _L), ("out", _P), ("ldo", _I), ("C", _I), ("gather", _I)]
@@ -86,6 +92,7 @@ SIGNATURES = {
     "hhrl_mlp3_slab_floats": (_L, [_I, _I, _I]),
     "hhrl_mlp3_forward_group": (_I, [_P, _I, _I, _P]),
     "hhrl_mlp3_backward_group": (_I, [_P, _I, _I, _P]),
+    "hhrl_mlp3_backward_group_adam": (_I, [_P, _I, _I, _P, _P]),
     "hhrl_sum_pool": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     "hhrl_broadcast_rows": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     "hhrl_copy2d": (_I, [_P, _I, _P, _I, _I, _I, _P]),
@@ -108,6 +115,7 @@ SIGNATURES = {
     "hhrl_td3_target_q": (_I, [_P, _P, _P, _I, _F, _P, _I, _P]),
     "hhrl_twin_mse": (_I, [_P, _P, _P, _F, _P, _P, _P, _I, _P]),
     "hhrl_td3_target_mse": (_I, [_P, _P, _P, _I, _F, _P, _P, _F, _P, _P, _P, _P, _I, _P]),
+    "hhrl_td3_target_mse_zeroed": (_I, [_P, _P, _P, _I, _F, _P, _P, _F, _P, _P, _P, _P, _I, _P]),
     "hhrl_lstm_workspace_floats": (_L, [_I, _I, _I, _I]),
     "hhrl_lstm_forward": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "hhrl_lstm_backward": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),

@@ -114,6 +114,9 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
   p = __fsub_rn(p, __fmul_rn(k.step_size, __fdiv_rn(m, denom)));
 }
 
+// soft update of a target network's copy of a parameter (om = 1 - tau), spelled out like adam_one
+__device__ __forceinline__ float polyak_one(float t, float p, float tau, float om) { return __fmaf_rn(tau, p, __fmul_rn(om, t)); }
+
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 // Optional per-launch timing (off by default).  When enabled through

@@ -219,7 +219,6 @@ __global__ void adam_stage_kernel(float* hyper, AdamK k) {
   }
 }
 
-__device__ __forceinline__ float polyak_one(float t, float p, float tau, float om) { return tau * p + om * t; }
 
 // VEC: float4 accesses (all base pointers 16-byte aligned) with a scalar tail.  POLYAK: the target network's
 // copy of each parameter moves towards the new value in the same pass (target = tau p + (1 - tau) target,
@@ -369,8 +368,9 @@ int hhrl_twin_mse(const float* q1, const float* q2, const float* y, float inv_n,
   return launch_status("twin_mse_kernel");
 }
 
-int hhrl_td3_target_mse(const float* q1t, const float* q2t, const float* r, int ldr, float gamma, const float* q1,
-                        const float* q2, float inv_n, float* y, float* loss, float* dq1, float* dq2, int B, void* stream) {
+static int td3_target_mse_impl(const float* q1t, const float* q2t, const float* r, int ldr, float gamma, const float* q1,
+                               const float* q2, float inv_n, float* y, float* loss, float* dq1, float* dq2, int B, bool zeroed,
+                               void* stream) {
   HHRL_REQUIRE(q1t && q2t && r && q1 && q2 && y && loss && dq1 && dq2, "td3_target_mse: null pointer");
   HHRL_REQUIRE(B > 0 && ldr >= 1, "td3_target_mse: B=%d ldr=%d", B, ldr);
   hipStream_t st = as_stream(stream);
@@ -381,11 +381,22 @@ int hhrl_td3_target_mse(const float* q1t, const float* q2t, const float* r, int 
     hipLaunchKernelGGL(td3_target_mse_kernel<true>, dim3(1), dim3(B >= 1024 ? 1024 : 256), 0, st, q1t, q2t, r, ldr, gamma, q1, q2,
                        inv_n, y, loss, dq1, dq2, B);
   } else {
-    if (hipMemsetAsync(loss, 0, 2 * sizeof(float), st) != hipSuccess) return fail(HHRL_ERR_HIP, "td3_target_mse: memset failed");
+    if (!zeroed && hipMemsetAsync(loss, 0, 2 * sizeof(float), st) != hipSuccess)
+      return fail(HHRL_ERR_HIP, "td3_target_mse: memset failed");
     hipLaunchKernelGGL(td3_target_mse_kernel<false>, dim3(stream_grid(B)), dim3(256), 0, st, q1t, q2t, r, ldr, gamma, q1, q2,
                        inv_n, y, loss, dq1, dq2, B);
   }
   return launch_status("td3_target_mse_kernel");
+}
+
+int hhrl_td3_target_mse(const float* q1t, const float* q2t, const float* r, int ldr, float gamma, const float* q1,
+                        const float* q2, float inv_n, float* y, float* loss, float* dq1, float* dq2, int B, void* stream) {
+  return td3_target_mse_impl(q1t, q2t, r, ldr, gamma, q1, q2, inv_n, y, loss, dq1, dq2, B, false, stream);
+}
+
+int hhrl_td3_target_mse_zeroed(const float* q1t, const float* q2t, const float* r, int ldr, float gamma, const float* q1,
+                               const float* q2, float inv_n, float* y, float* loss, float* dq1, float* dq2, int B, void* stream) {
+  return td3_target_mse_impl(q1t, q2t, r, ldr, gamma, q1, q2, inv_n, y, loss, dq1, dq2, B, true, stream);
 }
 
 static int adam_launch(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2, double eps,

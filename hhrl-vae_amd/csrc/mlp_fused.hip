@@ -522,15 +522,49 @@ __global__ __launch_bounds__(NT, 1) void mlp3_backward_kernel(NetGroup grp, int 
   if (tid < N3) unsafeAtomicAdd(&g.gb3[tid], G.b3);
 }
 
+// Optimizer step that rides on the slab sum (p == nullptr: none): the flat parameter, moment and target buffers
+// share the layout of the flat gradient buffer at gbase, which holds every gradient tensor of the group.
+struct AdamRide {
+  const float* gbase;
+  float *p, *m, *v, *target;
+  const float* hyper;       // the eight scalars of the step, in device memory
+  float tau, om;
+};
+
 // Sum of the slab rows in workgroup order, added to the gradient buffers.  A workgroup owns 32 consecutive
 // parameters; its eight groups of 32 threads each sum every eighth row (eight loads in flight per thread),
 // the eight sums meet in LDS and are added in group order.  blockIdx.y = network.
-__global__ __launch_bounds__(256) void mlp3_slab_reduce_kernel(NetGroup grp, int rows) {
+// ADAM: the thread that completes a gradient element also applies the Adam step to its parameter (and moves the
+// target network's copy): the element's parameter and moments are requested before the slab rows, so they are
+// there when the sum is, and the optimizer takes no launch and no pass of its own.
+template <bool ADAM>
+__global__ __launch_bounds__(256) void mlp3_slab_reduce_kernel(NetGroup grp, int rows, AdamRide ar) {
   __shared__ float part[8][33];
   const Net& g = grp.in[blockIdx.y];
   if (g.slab == nullptr || g.gw1 == nullptr) return;
-  const int P = slab_floats(g.K0, g.N3);
+  const int K0 = g.K0, N3 = g.N3;
+  const int P = slab_floats(K0, N3);
   const int c = threadIdx.x & 31, grp8 = threadIdx.x >> 5, e = blockIdx.x * 32 + c;
+  const bool last = grp8 == 0 && e < P;
+  float* dst = nullptr;
+  float g0 = 0.f, p0 = 0.f, m0 = 0.f, v0 = 0.f, t0 = 0.f;
+  long off = 0;
+  if (last) {
+    dst = e < slab_b1(K0, N3)   ? g.gw1 + e
+          : e < slab_w2(K0, N3) ? g.gb1 + (e - slab_b1(K0, N3))
+          : e < slab_b2(K0, N3) ? g.gw2 + (e - slab_w2(K0, N3))
+          : e < slab_w3(K0, N3) ? g.gb2 + (e - slab_b2(K0, N3))
+          : e < slab_b3(K0, N3) ? g.gw3 + (e - slab_w3(K0, N3))
+                                : g.gb3 + (e - slab_b3(K0, N3));
+    g0 = *dst;
+    if (ADAM) {
+      off = dst - ar.gbase;
+      p0 = ar.p[off];
+      m0 = ar.m[off];
+      v0 = ar.v[off];
+      if (ar.target != nullptr) t0 = ar.target[off];
+    }
+  }
   float s = 0.f;
   if (e < P) {
     const float* p = g.slab + e;
@@ -546,18 +580,22 @@ __global__ __launch_bounds__(256) void mlp3_slab_reduce_kernel(NetGroup grp, int
   }
   part[grp8][c] = s;
   __syncthreads();
-  if (grp8 == 0 && e < P) {
+  if (last) {
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) t += part[k][c];
-    const int K0 = g.K0, N3 = g.N3;
-    float* dst = e < slab_b1(K0, N3)   ? g.gw1 + e
-                 : e < slab_w2(K0, N3) ? g.gb1 + (e - slab_b1(K0, N3))
-                 : e < slab_b2(K0, N3) ? g.gw2 + (e - slab_w2(K0, N3))
-                 : e < slab_w3(K0, N3) ? g.gb2 + (e - slab_b2(K0, N3))
-                 : e < slab_b3(K0, N3) ? g.gw3 + (e - slab_w3(K0, N3))
-                                       : g.gb3 + (e - slab_b3(K0, N3));
-    *dst += t;
+    const float gn = g0 + t;
+    *dst = gn;
+    if (ADAM) {
+      AdamK k;
+      k.step_size = ar.hyper[0]; k.beta1 = ar.hyper[1]; k.beta2 = ar.hyper[2]; k.one_minus_b1 = ar.hyper[3];
+      k.one_minus_b2 = ar.hyper[4]; k.bc2_sqrt = ar.hyper[5]; k.eps = ar.hyper[6]; k.gscale = ar.hyper[7];
+      adam_one(p0, gn, m0, v0, k);
+      ar.p[off] = p0;
+      ar.m[off] = m0;
+      ar.v[off] = v0;
+      if (ar.target != nullptr) ar.target[off] = polyak_one(t0, p0, ar.tau, ar.om);
+    }
   }
 }
 
@@ -655,14 +693,16 @@ int hhrl_mlp3_forward_group(const hhrl_mlp3_desc* d, int n, int M, void* stream)
   return launch_status("mlp3_forward_kernel");
 }
 
-int hhrl_mlp3_backward_group(const hhrl_mlp3_desc* d, int n, int M, void* stream) {
+// ride == nullptr: plain backward pass.  Otherwise the optimizer step of `ride` follows the gradients: inside the slab
+// sum when every network of the group hands its gradients over as slab rows, else as a launch of its own.
+static int mlp3_backward_impl(const hhrl_mlp3_desc* d, int n, int M, const hhrl_adam_ride* ride, void* stream) {
   NetGroup grp;
   HHRL_TRY(fill_group(grp, d, n, M, true));
   hipStream_t st = as_stream(stream);
   double flops = 0.0;
   for (int i = 0; i < n; ++i) flops += 4.0 * M * ((double)d[i].K0 * H + (double)H * H + (double)H * d[i].N3);
   const int tiles = ceil_div(M, ROWS), gx = grid_x(tiles, n);
-  bool slabs = false;
+  int n_slabs = 0;
   int pmax = 0;
   for (int i = 0; i < n; ++i) {
     const int P = slab_floats(d[i].K0, d[i].N3);
@@ -670,21 +710,56 @@ int hhrl_mlp3_backward_group(const hhrl_mlp3_desc* d, int n, int M, void* stream
       HHRL_REQUIRE(d[i].gslab_floats >= (long)gx * P, "mlp3_backward: network %d: slab of %ld floats, %ld needed (hhrl_mlp3_slab_floats)",
                    i, d[i].gslab_floats, (long)gx * P);
       grp.in[i].slab = d[i].gslab;
-      slabs = true;
+      ++n_slabs;
       pmax = P > pmax ? P : pmax;
     }
+  }
+  AdamRide ar{};
+  if (ride != nullptr) {
+    HHRL_REQUIRE(ride->grads && ride->params && ride->m && ride->v && ride->hyper_dev && ride->n > 0,
+                 "mlp3_backward_adam: null pointer or n=%ld", ride->n);
+    for (int i = 0; i < n; ++i) {
+      const hhrl_mlp3_desc& s = d[i];
+      HHRL_REQUIRE(s.gw1 != nullptr, "mlp3_backward_adam: network %d has no parameter gradients", i);
+      const float* gp[6] = {s.gw1, s.gb1, s.gw2, s.gb2, s.gw3, s.gb3};
+      const long gl[6] = {(long)H * s.K0, H, (long)H * H, H, (long)s.N3 * H, s.N3};
+      for (int t = 0; t < 6; ++t)
+        HHRL_REQUIRE(gp[t] >= ride->grads && gp[t] + gl[t] <= ride->grads + ride->n,
+                     "mlp3_backward_adam: network %d: gradient tensor %d lies outside the flat gradient buffer", i, t);
+    }
+    ar.gbase = ride->grads; ar.p = ride->params; ar.m = ride->m; ar.v = ride->v; ar.target = ride->target;
+    ar.hyper = ride->hyper_dev; ar.tau = (float)ride->tau; ar.om = (float)(1.0 - ride->tau);
   }
   {
     ProfScope ps("mlp3_backward_kernel", st, flops, 0.0);
     hipLaunchKernelGGL(mlp3_backward_kernel, dim3(gx, n), dim3(NT), 0, st, grp, M, tiles);
     HHRL_TRY(launch_status("mlp3_backward_kernel"));
   }
-  if (slabs) {
-    ProfScope ps("mlp3_slab_reduce_kernel", st, 0.0, 4.0 * n * (double)pmax * (gx + 2));
-    hipLaunchKernelGGL(mlp3_slab_reduce_kernel, dim3(ceil_div(pmax, 32), n), dim3(256), 0, st, grp, gx);
+  const bool fused = ride != nullptr && n_slabs == n;
+  if (n_slabs > 0) {
+    ProfScope ps("mlp3_slab_reduce_kernel", st, 0.0, 4.0 * n * (double)pmax * (gx + 2 + (fused ? 7 : 0)));
+    if (fused)
+      hipLaunchKernelGGL(mlp3_slab_reduce_kernel<true>, dim3(ceil_div(pmax, 32), n), dim3(256), 0, st, grp, gx, ar);
+    else
+      hipLaunchKernelGGL(mlp3_slab_reduce_kernel<false>, dim3(ceil_div(pmax, 32), n), dim3(256), 0, st, grp, gx, ar);
     HHRL_TRY(launch_status("mlp3_slab_reduce_kernel"));
   }
+  if (ride != nullptr && !fused) {
+    if (ride->target != nullptr)
+      return hhrl_adam_polyak_step_dev(ride->params, ride->grads, ride->m, ride->v, ride->n, ride->hyper_dev, ride->target,
+                                       ride->tau, stream);
+    return hhrl_adam_step_dev(ride->params, ride->grads, ride->m, ride->v, ride->n, ride->hyper_dev, stream);
+  }
   return HHRL_OK;
+}
+
+int hhrl_mlp3_backward_group(const hhrl_mlp3_desc* d, int n, int M, void* stream) {
+  return mlp3_backward_impl(d, n, M, nullptr, stream);
+}
+
+int hhrl_mlp3_backward_group_adam(const hhrl_mlp3_desc* d, int n, int M, const hhrl_adam_ride* ride, void* stream) {
+  HHRL_REQUIRE(ride != nullptr, "mlp3_backward_group_adam: null optimizer description");
+  return mlp3_backward_impl(d, n, M, ride, stream);
 }
 
 #ifdef HHRL_STAMPS

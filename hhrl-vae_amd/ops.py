@@ -141,8 +141,16 @@ def mlp3_forward_group(descs, M: int) -> None:
     check(_lib.load().hhrl_mlp3_forward_group(descs, len(descs), M, _lib.stream_ptr()))
 
 
-def mlp3_backward_group(descs, M: int) -> None:
-    check(_lib.load().hhrl_mlp3_backward_group(descs, len(descs), M, _lib.stream_ptr()))
+def mlp3_backward_group(descs, M: int, ride=None) -> None:
+    """ride = (FlatAdam, hyper_ptr, target FlatBuffer or None, tau): the optimizer's step (and the target's soft
+    update) follows the gradients in the same call; the group's networks must be all of that optimizer's parameters."""
+    if ride is None:
+        check(_lib.load().hhrl_mlp3_backward_group(descs, len(descs), M, _lib.stream_ptr()))
+        return
+    opt, hyper, target, tau = ride
+    r = _lib.AdamRide(opt.g.base_ptr, opt.p.base_ptr, opt.m.base_ptr, opt.v.base_ptr, opt.p.layout.size, hyper,
+                      target.base_ptr if target is not None else None, float(tau))
+    check(_lib.load().hhrl_mlp3_backward_group_adam(descs, len(descs), M, C.byref(r), _lib.stream_ptr()))
 
 
 LSTM_KEYS = ["lstm_layer.weight_ih_l0", "lstm_layer.weight_hh_l0", "lstm_layer.bias_ih_l0", "lstm_layer.bias_hh_l0",

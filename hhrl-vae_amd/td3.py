@@ -150,17 +150,18 @@ class ActorNet:
         self.l2.fwd(P(w.h1), self.h[0], P(w.h2), self.h[1], B)
         self.l3.fwd(P(w.h2), self.h[1], out, ld_out, B)
 
-    def backward(self, B: int, out: int, ld_out: int, d_out: int, ld_dout: int, lstm: bool = True) -> None:
+    def backward(self, B: int, out: int, ld_out: int, d_out: int, ld_dout: int, lstm: bool = True, ride=None) -> bool:
         """Gradients of the most recent forward(B, ...) into this actor's flat
         gradient buffer (added; the caller zeroes it).  lstm=False leaves the
-        BPTT to the caller (lstm_bwd_item)."""
+        BPTT to the caller (lstm_bwd_item).  ride = (hyper_ptr, target FlatBuffer or None, tau): the optimizer step
+        may follow inside the same call (fused networks only); returns True when it did."""
         w = self.work(B)
         if self.mlp3 is not None:
             d = ops.mlp3_descs(1)
             self.fused_desc(d[0], B, out, ld_out)
             self.mlp3.grads(d[0], d_out, ld_dout, 0.0, True, None, 0, self.mlp3.slab(B, self.dev))
-            ops.mlp3_backward_group(d, B)
-            return
+            ops.mlp3_backward_group(d, B, (self.opt,) + tuple(ride) if ride is not None else None)
+            return ride is not None
         self.l3.bwd(P(w.h2), self.h[1], out, ld_out, d_out, ld_dout, P(w.d_h2), self.h[1], B)
         self.l2.bwd(P(w.h1), self.h[0], P(w.h2), self.h[1], P(w.d_h2), self.h[1], P(w.d_h1), self.h[0], B)
         if self.lstm is not None:
@@ -169,6 +170,7 @@ class ActorNet:
                 self.lstm.bwd(P(w.d_xin), self.d_in, w.lstm_ws, B)
         else:
             self.l1.bwd(w.x, w.ldx, P(w.h1), self.h[0], P(w.d_h1), self.h[0], None, 0, B)
+        return False
 
 
 class _CriticWork:
@@ -339,13 +341,16 @@ class CriticNet:
             self.lstms[k].bwd(P(w.d_xu, self.feat_cols[k]), self.D, w.lstm_ws[k], B)
 
     def backward(self, B: int, both_heads: bool, param_grads: bool, lstms: bool = True,
-                 dq_const: Optional[float] = None, policy_input: bool = False, dx_cols: Optional[Tuple[int, int]] = None) -> None:
+                 dq_const: Optional[float] = None, policy_input: bool = False, dx_cols: Optional[Tuple[int, int]] = None,
+                 ride=None) -> bool:
         """Back-propagates w.d_q1 (and w.d_q2) to w.d_xu; with param_grads also
         into the critic's gradient buffer (its LSTMs too unless lstms=False:
         the caller then runs lstm_backward per stream).  dq_const: dL/dQ1 is
         this constant for every row (the gradient of -mean Q1) instead of w.d_q1.  dx_cols = (first column, count):
         only those columns of w.d_xu are wanted (one actor's action columns on a policy step); honoured where it
-        saves work, else the whole of w.d_xu is written."""
+        saves work, else the whole of w.d_xu is written.  ride = (hyper_ptr, target FlatBuffer or None, tau): the
+        optimizer step may follow inside the same call (both fused heads with their parameter gradients: all of the
+        optimizer's parameters); returns True when it did."""
         w = self.work(B)
         h0, h1 = self.h
         has_lstm = any(l is not None for l in self.lstms)
@@ -360,8 +365,9 @@ class CriticNet:
                 self.mlp3[1].desc(d[1], P(w.xu), self.D, P(w.q2), 1, P(w.b1), P(w.b2))
                 self.mlp3[1].grads(d[1], P(w.d_q2), 1, 0.0, param_grads, None, 0,
                                    self.mlp3[1].slab(B, self.dev) if param_grads else None)
-            ops.mlp3_backward_group(d, B)
-            return
+            rides = ride is not None and both_heads and param_grads
+            ops.mlp3_backward_group(d, B, (self.opt,) + tuple(ride) if rides else None)
+            return rides
         d_q1 = P(w.d_q1)
         assert not policy_input, "the policy step's own input buffer is used with the fused three-layer heads only"
         if dq_const is not None and not both_heads and not param_grads and self.l3.N == 1:
@@ -850,6 +856,7 @@ class TD3Learner:
         # zero_grad of the critic (algorithm.py:805) and, on a policy step, of every actor (:822; nothing touches an
         # actor's gradient before its own backward pass) ride in the same launch
         cq.add_zero(c.opt.g.base_ptr, c.opt.g.data.numel())
+        cq.add_zero(P(self._loss), 2)               # the two critic losses are accumulated by the launch that forms them
         if policy:
             for a in self.actors:
                 cq.add_zero(a.opt.g.base_ptr, a.opt.g.data.numel())
@@ -895,17 +902,18 @@ class TD3Learner:
         # -- critic step: :1341-1350 / 799-808; target value, both losses and their gradients in one launch
         if not heads_early:
             c.heads(B)
-        check(lib.hhrl_td3_target_mse(P(cw_t.q1), P(cw_t.q2), R(self.col_reward), W, fam.gamma, P(cw.q1), P(cw.q2), inv_n,
+        check(lib.hhrl_td3_target_mse_zeroed(P(cw_t.q1), P(cw_t.q2), R(self.col_reward), W, fam.gamma, P(cw.q1), P(cw.q2), inv_n,
                                       P(y), P(self._loss), P(cw.d_q1), P(cw.d_q2), B, sp))
-        c.backward(B, both_heads=True, param_grads=True, lstms=False)
+        # on a policy step the soft updates (:1361-1364 / 827-834) ride on the optimizer launches: nothing
+        # between a network's step and the end of the update reads its target.  On one device (no gradient
+        # exchange between backward pass and step) a fused network's step rides on its backward call in turn.
+        local = self.world_size == 1
+        c_ride = (P(st.hyper[0]), self.critic_target.params if policy else None, fam.tau)
+        stepped = c.backward(B, both_heads=True, param_grads=True, lstms=False, ride=c_ride if local else None)
         self._lstm_backward([c.lstm_bwd_item(k, B) for k in range(n_str)], B)
         self._allreduce(c.opt.g)
-        # on a policy step the soft updates (:1361-1364 / 827-834) ride on the optimizer launches: nothing
-        # between a network's step and the end of the update reads its target
-        if policy:
-            c.opt.step_dev(P(st.hyper[0]), self.critic_target.params, fam.tau)
-        else:
-            c.opt.step_dev(P(st.hyper[0]))
+        if not stepped:
+            c.opt.step_dev(*c_ride)
 
         # -- delayed policy step: :1353-1366 / 811-838
         if policy:
@@ -926,11 +934,14 @@ class TD3Learner:
                     c.heads(B, q1_only=True, policy_input=ahead, hidden_only=True)
                     c.backward(B, both_heads=False, param_grads=False, dq_const=-inv_n, policy_input=ahead,
                                dx_cols=(c.act_cols[i], fam.a_dims[i]))
-                a.backward(B, P(xu_act, c.act_cols[i]), c.D, P(cw.d_xu, c.act_cols[i]), c.D, lstm=False)
+                a_ride = (P(st.hyper[1 + i]), self.actor_targets[i].params, fam.tau)
+                stepped = a.backward(B, P(xu_act, c.act_cols[i]), c.D, P(cw.d_xu, c.act_cols[i]), c.D, lstm=False,
+                                     ride=a_ride if local else None)
                 if a.lstm is not None:
                     self._lstm_backward([a.lstm_bwd_item(B)], B)
                 self._allreduce(a.opt.g)
-                a.opt.step_dev(P(st.hyper[1 + i]), self.actor_targets[i].params, fam.tau)
+                if not stepped:
+                    a.opt.step_dev(*a_ride)
                 if n + 1 < len(order):                # later actors see this actor's new policy
                     a.forward(B, obs[i][0], W, goal, W, P(cw.xu, c.act_cols[i]), c.D, inputs_done=True, no_backward=True)
 

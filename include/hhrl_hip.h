@@ -37,7 +37,7 @@ extern "C" {
 /* The ABI version this header describes; hhrl_version() returns the one the library was built with.  A binding checks
  * that they agree before it passes descriptor structs (their layout is part of the ABI).
  * 101: hhrl_lstm_desc gained `no_backward`; hhrl_gather_copy_group, hhrl_randn_fill, hhrl_vae_learn_steps added. */
-#define HHRL_ABI_VERSION 101
+#define HHRL_ABI_VERSION 102
 int hhrl_version(void);
 const char* hhrl_last_error(void);
 
@@ -262,6 +262,11 @@ int hhrl_twin_mse(const float* q1, const float* q2, const float* y, float inv_n,
 int hhrl_td3_target_mse(const float* q1t, const float* q2t, const float* r, int ldr, float gamma,
                         const float* q1, const float* q2, float inv_n, float* y, float* loss,
                         float* dq1, float* dq2, int B, void* stream);
+/* The same for a caller that has already set loss[0..1] to zero on the stream (e.g. inside the launch that stages
+ * the minibatch, hhrl_gather_copy_group): large batches then take no memset node of their own. */
+int hhrl_td3_target_mse_zeroed(const float* q1t, const float* q2t, const float* r, int ldr, float gamma,
+                               const float* q1, const float* q2, float inv_n, float* y, float* loss,
+                               float* dq1, float* dq2, int B, void* stream);
 
 /* ------------------------------------------------- three dense layers, fused
  * y = act3(W3 relu(W2 relu(W1 x + b1) + b2) + b3) as one launch per direction for a GROUP of
@@ -300,6 +305,21 @@ int hhrl_mlp3_supported(int K0, int H1, int H2, int N3);
 long hhrl_mlp3_slab_floats(int K0, int N3, int M);   /* 0: the atomics path serves this M */
 int hhrl_mlp3_forward_group(const hhrl_mlp3_desc* nets, int n, int M, void* stream);
 int hhrl_mlp3_backward_group(const hhrl_mlp3_desc* nets, int n, int M, void* stream);
+/* hhrl_mlp3_backward_group followed by the optimizer step of the group's networks: `*_optimizer.step()` right
+ * after `backward()` (algorithm.py:806-808, 823-824, 1348-1350, 1356-1357) and, with `target`, the soft update of
+ * the target network (:827-834, 1361-1364), i.e. hhrl_adam_step_dev / hhrl_adam_polyak_step_dev over the n floats
+ * of the flat buffers.  The group's gradient tensors must be ALL of the flat gradient buffer `grads` apart from
+ * zero padding (one optimizer whose parameters are exactly these networks).  When every network of the group hands
+ * its gradients over as slab rows, the step is applied by the launch that sums the slab (no launch and no pass over
+ * the buffers of its own); otherwise it follows as a separate launch.  Same bits either way. */
+typedef struct {
+  const float* grads;            /* flat gradient buffer: holds gw1..gb3 of every network of the group */
+  float *params, *m, *v;         /* flat buffers of the same layout */
+  long n;                        /* floats in each */
+  const float* hyper_dev;        /* the eight scalars of the step in device memory (hhrl_adam_stage) */
+  float* target; double tau;     /* optional (null: none): target = tau*params + (1-tau)*target */
+} hhrl_adam_ride;
+int hhrl_mlp3_backward_group_adam(const hhrl_mlp3_desc* nets, int n, int M, const hhrl_adam_ride* opt, void* stream);
 
 /* -------------------------------------------------------------------- LSTM
  * Bidirectional one-layer LSTM over a window of T steps, last time index only,

@@ -390,9 +390,94 @@ def test_td3_target_mse_equals_two_launches(env, B):
     L.check(lib.hhrl_td3_target_mse(t1.data_ptr(), t2.data_ptr(), r_ptr, 5, 0.9, q1.data_ptr(), q2.data_ptr(), 1.0 / B,
                                     y_b.data_ptr(), lb.data_ptr(), d1b.data_ptr(), d2b.data_ptr(), B, st))
     assert torch.equal(y_a, y_b) and torch.equal(d1a, d1b) and torch.equal(d2a, d2b)
+    # the form for a caller that zeroed the loss itself
+    lc = torch.zeros(2, device=dev)
+    y_c, d1c, d2c = (torch.zeros(B, 1, device=dev) for _ in range(3))
+    L.check(lib.hhrl_td3_target_mse_zeroed(t1.data_ptr(), t2.data_ptr(), r_ptr, 5, 0.9, q1.data_ptr(), q2.data_ptr(), 1.0 / B,
+                                           y_c.data_ptr(), lc.data_ptr(), d1c.data_ptr(), d2c.data_ptr(), B, st))
+    assert torch.equal(y_c, y_b) and torch.equal(d1c, d1b) and torch.equal(d2c, d2b)
+    scaled_close("loss (zeroed by the caller)", lc.cpu().numpy(), la.cpu().numpy(), rtol=1e-5)
     want = rows[:, 3:4] + 0.9 * torch.minimum(t1, t2)
     scaled_close("y", y_b.cpu().numpy(), want.cpu().numpy(), rtol=1e-6)
     scaled_close("loss", lb.cpu().numpy(), la.cpu().numpy(), rtol=1e-5)
+
+
+@pytest.mark.parametrize("M,polyak", [(4096, True), (4096, False), (300, True), (64, True)])
+def test_mlp3_backward_group_adam_equals_two_calls(env, M, polyak):
+    """hhrl_mlp3_backward_group_adam against hhrl_mlp3_backward_group followed by hhrl_adam_step_dev /
+    hhrl_adam_polyak_step_dev on flat buffers that hold two networks (the two heads of a critic): the same bits in
+    the gradients, parameters, both moments and the target copy, whether the step rides on the slab sum (M >= 256)
+    or follows as a launch of its own (M = 64); padding between the tensors is left alone."""
+    lib, L, dev = env
+    K0, N3, n = 11, 1, 2
+    g = torch.Generator().manual_seed(1000 + M)
+    sizes = [128 * K0, 128, 128 * 128, 128, N3 * 128, N3]
+    offs, total = [], 0
+    for i in range(n):
+        for sz in sizes:
+            offs.append(total)
+            total += -(-sz // 64) * 64
+    flat = lambda scale: (torch.randn(total, generator=g) * scale).to(dev)
+    p0, m0, v0, t0 = flat(0.1), flat(0.01), flat(0.01).abs(), flat(0.1)
+    x = torch.randn(M, K0, generator=g).to(dev)
+    dy = [torch.randn(M, N3, generator=g).to(dev) for _ in range(n)]
+    hyper = torch.zeros(8, device=dev)
+    st = L.stream_ptr()
+    L.check(lib.hhrl_adam_stage(hyper.data_ptr(), 1e-3, 0.9, 0.999, 1e-8, 7, 1.0, st))
+    results = []
+    for fused in (False, True):
+        p, m, v, t = p0.clone(), m0.clone(), v0.clone(), t0.clone()
+        gr = torch.zeros(total, device=dev)
+        descs = (L.Mlp3Desc * n)()
+        keep = []
+        for i in range(n):
+            d = descs[i]
+            o = offs[6 * i: 6 * i + 6]
+            P_ = lambda buf, k: buf.data_ptr() + 4 * o[k]
+            d.x, d.ldx, d.K0 = x.data_ptr(), K0, K0
+            d.w1, d.b1, d.w2, d.b2, d.w3, d.b3 = [P_(p, k) for k in range(6)]
+            h1, h2, y = torch.empty(M, 128, device=dev), torch.empty(M, 128, device=dev), torch.empty(M, N3, device=dev)
+            d.N3, d.act3, d.h1, d.h2, d.y, d.ldy = N3, 0, h1.data_ptr(), h2.data_ptr(), y.data_ptr(), N3
+            d.dy, d.lddy, d.dy_const = dy[i].data_ptr(), N3, 0.0
+            d.gw1, d.gb1, d.gw2, d.gb2, d.gw3, d.gb3 = [P_(gr, k) for k in range(6)]
+            n_slab = lib.hhrl_mlp3_slab_floats(K0, N3, M)
+            slab = torch.full((max(n_slab, 1),), float("nan"), device=dev)
+            if n_slab:
+                d.gslab, d.gslab_floats = slab.data_ptr(), n_slab
+            keep.append((h1, h2, y, slab))
+        L.check(lib.hhrl_mlp3_forward_group(descs, n, M, st))
+        tp = t.data_ptr() if polyak else None
+        if fused:
+            ride = L.AdamRide(gr.data_ptr(), p.data_ptr(), m.data_ptr(), v.data_ptr(), total, hyper.data_ptr(), tp, 0.005)
+            L.check(lib.hhrl_mlp3_backward_group_adam(descs, n, M, C.byref(ride), st))
+        else:
+            L.check(lib.hhrl_mlp3_backward_group(descs, n, M, st))
+            if polyak:
+                L.check(lib.hhrl_adam_polyak_step_dev(p.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), total,
+                                                      hyper.data_ptr(), tp, 0.005, st))
+            else:
+                L.check(lib.hhrl_adam_step_dev(p.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), total, hyper.data_ptr(), st))
+        torch.cuda.synchronize()
+        results.append((gr, p, m, v, t))
+    names = ("gradients", "parameters", "exp_avg", "exp_avg_sq", "target")
+    covered = torch.zeros(total, dtype=torch.bool, device=dev)
+    for o, sz in zip(offs, sizes * n):
+        covered[o: o + sz] = True
+    for name, a, b in zip(names, results[0], results[1]):
+        if M >= 256:
+            # slab sums are the same bits on every run; outside the tensors the riding step touches nothing, the
+            # stand-alone one moves padding by its (nonzero, random here) moments
+            assert torch.equal(a[covered], b[covered]), name
+        else:
+            # float atomics add the workgroups' shares in an order that differs between runs
+            assert torch.allclose(a[covered], b[covered], rtol=1e-4, atol=1e-6), name
+    assert not torch.equal(results[1][1], p0) and (polyak != torch.equal(results[1][4], t0))
+    if M >= 256:
+        assert torch.equal(results[1][1][~covered], p0[~covered])
+    # a gradient tensor outside the flat buffer is refused
+    ride = L.AdamRide(gr.data_ptr() + 4 * 64, p.data_ptr(), m.data_ptr(), v.data_ptr(), total - 64, hyper.data_ptr(), None, 0.0)
+    assert lib.hhrl_mlp3_backward_group_adam(descs, n, M, C.byref(ride), st) != 0
+    assert b"outside" in lib.hhrl_last_error()
 
 
 @pytest.mark.parametrize("B,T,o,H", [(9, 5, 7, 12), (64, 10, 13, 128), (64, 10, 25, 128), (3, 1, 4, 8), (130, 4, 5, 8),

@@ -34,6 +34,13 @@ def main():
         f = net.launch_forms()
         if it >= 30 and len(f) == n_chains and "tuning" not in f.values():
             break
+    # ... and until the device has been busy with this update for half a second, as bench.py does: a chain bound by
+    # the GPU is then timed at the clocks the chip settles on
+    torch.cuda.synchronize()
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < 0.5:
+        net.learn()
+        it += 1
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(updates):
