@@ -19,7 +19,7 @@ _L = C.c_long
 _F = C.c_float
 _D = C.c_double
 
-ABI_VERSION = 102            # HHRL_ABI_VERSION of include/hhrl_hip.h
+ABI_VERSION = 103            # HHRL_ABI_VERSION of include/hhrl_hip.h
 
 
 class LstmDesc(C.Structure):
@@ -48,7 +48,9 @@ class Mlp3Desc(C.Structure):
                 ("gw1", _P), ("gb1", _P), ("gw2", _P), ("gb2", _P), ("gw3", _P), ("gb3", _P),
                 ("dx", _P), ("lddx", _I),
                 ("smooth_eps", _P), ("y2", _P), ("ldy2", _I), ("forward_dx", _I),
-                ("gslab", _P), ("gslab_floats", _L)]
+                ("gslab", _P), ("gslab_floats", _L),
+                ("mse_q1t", _P), ("mse_q2t", _P), ("mse_r", _P), ("mse_ldr", _I), ("mse_gamma", _F), ("mse_inv_n", _F),
+                ("mse_loss", _P), ("mse_target", _P)]
 
 
 MLP3_GROUP_MAX = 8

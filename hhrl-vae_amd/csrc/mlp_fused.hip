@@ -50,6 +50,13 @@ struct Net {
   float* slab;            // backward, optional: [gridDim.x][slab_floats(K0, N3)] partial parameter gradients instead of atomics
   float dy_const;
   int ldx, ldy, lddy, lddx, K0, N3, act3, ldy2, forward_dx;
+  // backward, optional (tq1 != nullptr; N3 == 1): dL/dy is formed here from the TD3 target, dy = 2 inv_n (y - target) with
+  // target = tr[row * ldr] + gamma * min(tq1[row], tq2[row]); inv_n * sum (y - target)^2 is added to *tloss, the
+  // target stored to ty (optional)
+  const float *tq1, *tq2, *tr;
+  float *tloss, *ty;
+  int ldr;
+  float gamma, inv_n;
 };
 // order of a network's parameter gradients inside a slab row
 __host__ __device__ inline int slab_w1(int, int) { return 0; }
@@ -58,7 +65,9 @@ __host__ __device__ inline int slab_w2(int K0, int) { return H * K0 + H; }
 __host__ __device__ inline int slab_b2(int K0, int) { return H * K0 + H + H * H; }
 __host__ __device__ inline int slab_w3(int K0, int) { return H * K0 + 2 * H + H * H; }
 __host__ __device__ inline int slab_b3(int K0, int N3) { return H * K0 + 2 * H + H * H + N3 * H; }
-__host__ __device__ inline int slab_floats(int K0, int N3) { return H * K0 + 2 * H + H * H + N3 * H + N3; }
+// a slab row ends with one more entry, the workgroup's share of the loss (read only when the network forms one)
+__host__ __device__ inline int slab_loss(int K0, int N3) { return H * K0 + 2 * H + H * H + N3 * H + N3; }
+__host__ __device__ inline int slab_floats(int K0, int N3) { return slab_loss(K0, N3) + 1; }
 struct NetGroup { Net in[kMaxNets]; };
 
 // LDS map (floats).  Row strides are 4 mod 32 banks and a multiple of four floats: 16-byte reads of a row
@@ -154,6 +163,7 @@ struct TileIn {
   float x[ROWS * KMAX / NT];      // 2
   float4 h1, h2;                  // backward only
   float d3, y3;                   // backward only: dL/dy and the output y, combined by commit_bwd
+  float t1, t2, tr;               // backward only: the target critic's two values and the reward of the row (TD3 target)
   bool okd;
 };
 __device__ __forceinline__ void request_x(TileIn& T, const Net& g, int row0, int M, int tid, int K0p) {
@@ -181,20 +191,34 @@ __device__ __forceinline__ void request_bwd(TileIn& T, const Net& g, int row0, i
   // exists (the first of h1) and do not use it: no branch around a request, and no generic-address load.
   const int dr = tid / N3p, dc = tid - dr * N3p;
   const bool okd = dr < ROWS && dc < g.N3 && row0 + dr < M;
+  const bool tgt = g.tq1 != nullptr, use_y = g.act3 != HHRL_ACT_NONE || tgt;
   const float* dyp = g.dy ? g.dy : g.h1;
-  const float* yp = g.act3 != HHRL_ACT_NONE ? g.y : g.h1;
+  const float* yp = use_y ? g.y : g.h1;
   T.d3 = dyp[okd && g.dy ? (long)(row0 + dr) * g.lddy + dc : 0];
-  T.y3 = yp[okd && g.act3 != HHRL_ACT_NONE ? (long)(row0 + dr) * g.ldy + dc : 0];
+  T.y3 = yp[okd && use_y ? (long)(row0 + dr) * g.ldy + dc : 0];
+  const long ti = okd && tgt ? row0 + dr : 0;
+  T.t1 = (tgt ? g.tq1 : g.h1)[ti];
+  T.t2 = (tgt ? g.tq2 : g.h1)[ti];
+  T.tr = (tgt ? g.tr : g.h1)[ti * (tgt ? g.ldr : 0)];
   T.okd = okd;
 }
-__device__ __forceinline__ void commit_bwd(float* lds, const TileIn& T, const Net& g, int tid, int N3p) {
+// sq: this thread's sum of squared differences to the TD3 target so far (networks that form their own dL/dy)
+__device__ __forceinline__ void commit_bwd(float* lds, const TileIn& T, const Net& g, int tid, int N3p, int row0, float& sq) {
   const int rr = tid >> 5, c4 = (tid & 31) * 4;
   *reinterpret_cast<float4*>(lds + L_A1 + rr * LDA + c4) = T.h1;
   *reinterpret_cast<float4*>(lds + L_A2 + rr * LDA + c4) = T.h2;
   const int dr = tid / N3p, dc = tid - dr * N3p;
   float v = 0.f;
   if (T.okd) {
-    v = g.dy ? T.d3 : g.dy_const;
+    if (g.tq1 != nullptr) {                 // same arithmetic as td3_target_mse_kernel
+      const float yi = T.tr + g.gamma * fminf(T.t1, T.t2);
+      const float d = T.y3 - yi;
+      sq += d * d;
+      v = 2.f * g.inv_n * d;
+      if (g.ty != nullptr) g.ty[row0 + dr] = yi;
+    } else {
+      v = g.dy ? T.d3 : g.dy_const;
+    }
     if (g.act3 != HHRL_ACT_NONE) v *= act_grad_from_output(T.y3, g.act3);
   }
   if (dr < ROWS) lds[L_D3 + dr * LDD + dc] = v;
@@ -454,9 +478,10 @@ __global__ __launch_bounds__(NT, 1) void mlp3_backward_kernel(NetGroup grp, int 
 #pragma unroll
   for (int c = 0; c < NBX; ++c) G.w1[c] = zero4();
   G.b1 = G.b2 = G.b3 = 0.f;
+  float sq = 0.f;
   for (; tile < tiles; tile += gridDim.x) {
     commit_x(lds, T, tid, K0p);
-    commit_bwd(lds, T, g, tid, N3p);
+    commit_bwd(lds, T, g, tid, N3p, tile * ROWS, sq);
     lds_barrier();
     MLP_STAMP(1, sn++);
     if (tile + (int)gridDim.x < tiles) {
@@ -465,6 +490,23 @@ __global__ __launch_bounds__(NT, 1) void mlp3_backward_kernel(NetGroup grp, int 
     }
     tile_backward(lds, g, W, G, pg, want_dx, tile * ROWS, M, tid, nm1, nb3);
     MLP_STAMP(1, sn++);
+  }
+  if (g.tq1 != nullptr) {
+    // ---- this workgroup's share of the loss: the rows' squares summed in row order (the tile's LDS is free), then
+    // one entry of the slab row (summed with the others in workgroup order) or, without a slab, one atomic addition
+    const int dr = tid / N3p;
+    if (dr < ROWS && tid == dr * N3p) lds[dr] = sq;
+    lds_barrier();
+    if (tid == 0) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) s += lds[r];
+      s *= g.inv_n;
+      if (pg && g.slab != nullptr)
+        g.slab[(long)blockIdx.x * slab_floats(K0, N3) + slab_loss(K0, N3)] = s;
+      else
+        unsafeAtomicAdd(g.tloss, s);
+    }
   }
   if (!pg) return;
   // ---- this workgroup's share of the parameter gradients, handed over once
@@ -545,7 +587,8 @@ __global__ __launch_bounds__(256) void mlp3_slab_reduce_kernel(NetGroup grp, int
   const int K0 = g.K0, N3 = g.N3;
   const int P = slab_floats(K0, N3);
   const int c = threadIdx.x & 31, grp8 = threadIdx.x >> 5, e = blockIdx.x * 32 + c;
-  const bool last = grp8 == 0 && e < P;
+  const bool is_loss = e == slab_loss(K0, N3);          // the row's last entry: a share of the loss, when one is formed
+  const bool last = grp8 == 0 && e < P && !(is_loss && g.tq1 == nullptr);
   float* dst = nullptr;
   float g0 = 0.f, p0 = 0.f, m0 = 0.f, v0 = 0.f, t0 = 0.f;
   long off = 0;
@@ -555,9 +598,10 @@ __global__ __launch_bounds__(256) void mlp3_slab_reduce_kernel(NetGroup grp, int
           : e < slab_b2(K0, N3) ? g.gw2 + (e - slab_w2(K0, N3))
           : e < slab_w3(K0, N3) ? g.gb2 + (e - slab_b2(K0, N3))
           : e < slab_b3(K0, N3) ? g.gw3 + (e - slab_w3(K0, N3))
-                                : g.gb3 + (e - slab_b3(K0, N3));
+          : !is_loss            ? g.gb3 + (e - slab_b3(K0, N3))
+                                : g.tloss;
     g0 = *dst;
-    if (ADAM) {
+    if (ADAM && !is_loss) {
       off = dst - ar.gbase;
       p0 = ar.p[off];
       m0 = ar.m[off];
@@ -566,7 +610,7 @@ __global__ __launch_bounds__(256) void mlp3_slab_reduce_kernel(NetGroup grp, int
     }
   }
   float s = 0.f;
-  if (e < P) {
+  if (e < P && !(is_loss && g.tq1 == nullptr)) {
     const float* p = g.slab + e;
     int r = grp8;
     for (; r + 56 < rows; r += 64) {
@@ -586,7 +630,7 @@ __global__ __launch_bounds__(256) void mlp3_slab_reduce_kernel(NetGroup grp, int
     for (int k = 0; k < 8; ++k) t += part[k][c];
     const float gn = g0 + t;
     *dst = gn;
-    if (ADAM) {
+    if (ADAM && !is_loss) {
       AdamK k;
       k.step_size = ar.hyper[0]; k.beta1 = ar.hyper[1]; k.beta2 = ar.hyper[2]; k.one_minus_b1 = ar.hyper[3];
       k.one_minus_b2 = ar.hyper[4]; k.bc2_sqrt = ar.hyper[5]; k.eps = ar.hyper[6]; k.gscale = ar.hyper[7];
@@ -652,6 +696,13 @@ static int fill_group(NetGroup& grp, const hhrl_mlp3_desc* d, int n, int M, bool
     g.ldx = s.ldx; g.ldy = s.ldy; g.lddy = s.lddy; g.lddx = s.lddx; g.K0 = s.K0; g.N3 = s.N3; g.act3 = s.act3;
     g.forward_dx = backward ? 0 : s.forward_dx;
     g.slab = nullptr;
+    const bool tgt = backward && s.mse_q1t != nullptr;
+    if (tgt) {
+      HHRL_REQUIRE(s.N3 == 1 && s.y && !s.dy, "mlp3_backward: network %d: the TD3 target form needs N3 = 1, y and no dy", i);
+      HHRL_REQUIRE(s.mse_q2t && s.mse_r && s.mse_loss && s.mse_ldr >= 1, "mlp3_backward: network %d: incomplete TD3 target description", i);
+    }
+    g.tq1 = tgt ? s.mse_q1t : nullptr; g.tq2 = s.mse_q2t; g.tr = s.mse_r; g.tloss = s.mse_loss; g.ty = s.mse_target;
+    g.ldr = s.mse_ldr; g.gamma = s.mse_gamma; g.inv_n = s.mse_inv_n;
   }
   return HHRL_OK;
 }

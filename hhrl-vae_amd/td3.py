@@ -334,6 +334,10 @@ class CriticNet:
         ops.mlp3_forward_group(d, B)
         return True
 
+    def fused_target(self) -> bool:
+        """Whether backward(both_heads=True, param_grads=True, target=...) forms the critic loss inside its launch."""
+        return self.mlp3 is not None and not any(l is not None for l in self.lstms)
+
     def lstm_backward(self, k: int, B: int) -> None:
         """BPTT of stream k's LSTM from its columns of w.d_xu (independent of the other streams)."""
         w = self.work(B)
@@ -342,7 +346,7 @@ class CriticNet:
 
     def backward(self, B: int, both_heads: bool, param_grads: bool, lstms: bool = True,
                  dq_const: Optional[float] = None, policy_input: bool = False, dx_cols: Optional[Tuple[int, int]] = None,
-                 ride=None) -> bool:
+                 ride=None, target=None) -> bool:
         """Back-propagates w.d_q1 (and w.d_q2) to w.d_xu; with param_grads also
         into the critic's gradient buffer (its LSTMs too unless lstms=False:
         the caller then runs lstm_backward per stream).  dq_const: dL/dQ1 is
@@ -350,7 +354,9 @@ class CriticNet:
         only those columns of w.d_xu are wanted (one actor's action columns on a policy step); honoured where it
         saves work, else the whole of w.d_xu is written.  ride = (hyper_ptr, target FlatBuffer or None, tau): the
         optimizer step may follow inside the same call (both fused heads with their parameter gradients: all of the
-        optimizer's parameters); returns True when it did."""
+        optimizer's parameters); returns True when it did.  target = (q1t, q2t, reward, ld_reward, gamma, inv_n, loss,
+        y): with both fused heads the launch forms the TD3 target, both losses (added to loss[0..1], zeroed by the
+        caller) and dL/dQ itself instead of reading w.d_q1 / w.d_q2 (see fused_target())."""
         w = self.work(B)
         h0, h1 = self.h
         has_lstm = any(l is not None for l in self.lstms)
@@ -365,9 +371,16 @@ class CriticNet:
                 self.mlp3[1].desc(d[1], P(w.xu), self.D, P(w.q2), 1, P(w.b1), P(w.b2))
                 self.mlp3[1].grads(d[1], P(w.d_q2), 1, 0.0, param_grads, None, 0,
                                    self.mlp3[1].slab(B, self.dev) if param_grads else None)
+            if target is not None:
+                assert both_heads and dq_const is None
+                q1t, q2t, r, ldr, gamma, inv_n, loss, y = target
+                for k in (0, 1):
+                    d[k].dy, d[k].mse_q1t, d[k].mse_q2t, d[k].mse_r, d[k].mse_ldr = None, q1t, q2t, r, ldr
+                    d[k].mse_gamma, d[k].mse_inv_n, d[k].mse_loss, d[k].mse_target = gamma, inv_n, loss + 4 * k, y
             rides = ride is not None and both_heads and param_grads
             ops.mlp3_backward_group(d, B, (self.opt,) + tuple(ride) if rides else None)
             return rides
+        assert target is None, "the TD3 target is formed by the fused three-layer heads only (fused_target())"
         d_q1 = P(w.d_q1)
         assert not policy_input, "the policy step's own input buffer is used with the fused three-layer heads only"
         if dq_const is not None and not both_heads and not param_grads and self.l3.N == 1:
@@ -902,14 +915,19 @@ class TD3Learner:
         # -- critic step: :1341-1350 / 799-808; target value, both losses and their gradients in one launch
         if not heads_early:
             c.heads(B)
-        check(lib.hhrl_td3_target_mse_zeroed(P(cw_t.q1), P(cw_t.q2), R(self.col_reward), W, fam.gamma, P(cw.q1), P(cw.q2), inv_n,
-                                      P(y), P(self._loss), P(cw.d_q1), P(cw.d_q2), B, sp))
+        # (fused three-layer heads form the target, the losses and dL/dQ inside their backward launch)
+        c_target = None
+        if c.fused_target():
+            c_target = (P(cw_t.q1), P(cw_t.q2), R(self.col_reward), W, fam.gamma, inv_n, P(self._loss), P(y))
+        else:
+            check(lib.hhrl_td3_target_mse_zeroed(P(cw_t.q1), P(cw_t.q2), R(self.col_reward), W, fam.gamma, P(cw.q1), P(cw.q2), inv_n,
+                                                 P(y), P(self._loss), P(cw.d_q1), P(cw.d_q2), B, sp))
         # on a policy step the soft updates (:1361-1364 / 827-834) ride on the optimizer launches: nothing
         # between a network's step and the end of the update reads its target.  On one device (no gradient
         # exchange between backward pass and step) a fused network's step rides on its backward call in turn.
         local = self.world_size == 1
         c_ride = (P(st.hyper[0]), self.critic_target.params if policy else None, fam.tau)
-        stepped = c.backward(B, both_heads=True, param_grads=True, lstms=False, ride=c_ride if local else None)
+        stepped = c.backward(B, both_heads=True, param_grads=True, lstms=False, ride=c_ride if local else None, target=c_target)
         self._lstm_backward([c.lstm_bwd_item(k, B) for k in range(n_str)], B)
         self._allreduce(c.opt.g)
         if not stepped:

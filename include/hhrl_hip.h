@@ -37,7 +37,7 @@ extern "C" {
 /* The ABI version this header describes; hhrl_version() returns the one the library was built with.  A binding checks
  * that they agree before it passes descriptor structs (their layout is part of the ABI).
  * 101: hhrl_lstm_desc gained `no_backward`; hhrl_gather_copy_group, hhrl_randn_fill, hhrl_vae_learn_steps added. */
-#define HHRL_ABI_VERSION 102
+#define HHRL_ABI_VERSION 103
 int hhrl_version(void);
 const char* hhrl_last_error(void);
 
@@ -300,6 +300,13 @@ typedef struct {
    * enough rows, the workgroups hand their parameter gradients over as slab rows that a second launch sums in a
    * fixed order (same bits on every run) instead of adding them with float atomics. */
   float* gslab; long gslab_floats;
+  /* backward only, optional (mse_q1t non-null; N3 = 1, y given, dy null): the network is a critic head whose loss is the
+   * TD3 critic loss (algorithm.py:1329-1345 / 785-803).  The launch forms dL/dy itself, as hhrl_td3_target_mse does:
+   * target = mse_r[row*mse_ldr] + mse_gamma * min(mse_q1t[row], mse_q2t[row]);  dL/dy = 2*mse_inv_n*(y - target);
+   * *mse_loss += mse_inv_n * sum (y - target)^2 (zeroed by the caller; summed in a fixed order with a slab, by one
+   * atomic addition per workgroup without); mse_target, when given, receives the target [M]. */
+  const float *mse_q1t, *mse_q2t, *mse_r; int mse_ldr; float mse_gamma, mse_inv_n;
+  float* mse_loss; float* mse_target;
 } hhrl_mlp3_desc;
 int hhrl_mlp3_supported(int K0, int H1, int H2, int N3);
 long hhrl_mlp3_slab_floats(int K0, int N3, int M);   /* 0: the atomics path serves this M */

@@ -402,6 +402,70 @@ def test_td3_target_mse_equals_two_launches(env, B):
     scaled_close("loss", lb.cpu().numpy(), la.cpu().numpy(), rtol=1e-5)
 
 
+@pytest.mark.parametrize("M", [4096, 1000, 64, 5])
+def test_mlp3_backward_td3_target_equals_two_calls(env, M):
+    """The backward launch of two critic heads that forms the TD3 target, both losses and dL/dQ itself (mse_* fields)
+    against hhrl_td3_target_mse followed by the plain backward launch: the same target, the same bits in every
+    parameter gradient with slabs (M >= 256; float atomics below add in an order of their own), the same losses."""
+    lib, L, dev = env
+    K0, n = 11, 2
+    g = torch.Generator().manual_seed(77 + M)
+    r = lambda *s: torch.randn(*s, generator=g)
+    x = r(M, K0).to(dev)
+    rows = r(M, 6).to(dev)                              # the reward is column 2 of a wider row
+    q1t, q2t = r(M, 1).to(dev), r(M, 1).to(dev)
+    ws = [[(r(128, K0) / K0 ** 0.5).to(dev), r(128).to(dev), (r(128, 128) / 128 ** 0.5).to(dev), r(128).to(dev),
+           (r(1, 128) / 128 ** 0.5).to(dev), r(1).to(dev)] for _ in range(n)]
+    st = L.stream_ptr()
+    out = []
+    for own in (False, True):
+        descs = (L.Mlp3Desc * n)()
+        keep, grads = [], []
+        loss, y = torch.zeros(2, device=dev), torch.full((M,), 9.0, device=dev)
+        dq = [torch.zeros(M, 1, device=dev) for _ in range(n)]
+        for i in range(n):
+            d = descs[i]
+            d.x, d.ldx, d.K0 = x.data_ptr(), K0, K0
+            d.w1, d.b1, d.w2, d.b2, d.w3, d.b3 = [w.data_ptr() for w in ws[i]]
+            h1, h2, q = torch.empty(M, 128, device=dev), torch.empty(M, 128, device=dev), torch.empty(M, 1, device=dev)
+            d.N3, d.act3, d.h1, d.h2, d.y, d.ldy = 1, 0, h1.data_ptr(), h2.data_ptr(), q.data_ptr(), 1
+            gd = [torch.zeros_like(w) for w in ws[i]]
+            d.gw1, d.gb1, d.gw2, d.gb2, d.gw3, d.gb3 = [t.data_ptr() for t in gd]
+            n_slab = lib.hhrl_mlp3_slab_floats(K0, 1, M)
+            slab = torch.full((max(n_slab, 1),), float("nan"), device=dev)
+            if n_slab:
+                d.gslab, d.gslab_floats = slab.data_ptr(), n_slab
+            keep.append((h1, h2, q, slab))
+            grads.append(gd)
+        L.check(lib.hhrl_mlp3_forward_group(descs, n, M, st))
+        if own:
+            for i in range(n):
+                d = descs[i]
+                d.mse_q1t, d.mse_q2t, d.mse_r, d.mse_ldr = q1t.data_ptr(), q2t.data_ptr(), rows.data_ptr() + 4 * 2, 6
+                d.mse_gamma, d.mse_inv_n, d.mse_loss, d.mse_target = 0.9, 1.0 / M, loss.data_ptr() + 4 * i, y.data_ptr()
+        else:
+            L.check(lib.hhrl_td3_target_mse(q1t.data_ptr(), q2t.data_ptr(), rows.data_ptr() + 4 * 2, 6, 0.9, keep[0][2].data_ptr(),
+                                            keep[1][2].data_ptr(), 1.0 / M, y.data_ptr(), loss.data_ptr(), dq[0].data_ptr(),
+                                            dq[1].data_ptr(), M, st))
+            for i in range(n):
+                descs[i].dy, descs[i].lddy = dq[i].data_ptr(), 1
+        L.check(lib.hhrl_mlp3_backward_group(descs, n, M, st))
+        torch.cuda.synchronize()
+        out.append((loss, y, grads))
+    (la, ya, ga), (lb, yb, gb) = out
+    assert torch.equal(ya, yb)
+    scaled_close("losses", lb.cpu().numpy(), la.cpu().numpy(), rtol=1e-5)
+    for i in range(n):
+        for k, (a, b) in enumerate(zip(ga[i], gb[i])):
+            if M >= 256:
+                assert torch.equal(a, b), "gradient %d of head %d" % (k, i)
+            else:
+                scaled_close("gradient %d of head %d" % (k, i), b.cpu().numpy(), a.cpu().numpy(), atol_rel=1e-5)
+    # the form is refused for a wider output or together with a dy
+    descs[0].dy, descs[0].lddy = dq[0].data_ptr(), 1
+    assert lib.hhrl_mlp3_backward_group(descs, n, M, st) != 0 and b"TD3 target" in lib.hhrl_last_error()
+
+
 @pytest.mark.parametrize("M,polyak", [(4096, True), (4096, False), (300, True), (64, True)])
 def test_mlp3_backward_group_adam_equals_two_calls(env, M, polyak):
     """hhrl_mlp3_backward_group_adam against hhrl_mlp3_backward_group followed by hhrl_adam_step_dev /
