@@ -643,17 +643,25 @@ __global__ __launch_bounds__(256) void mlp3_slab_reduce_kernel(NetGroup grp, int
   }
 }
 
-// Workgroups per launch: as many as fill the chip once (256 CUs, one workgroup each), shared among the
-// networks of the group; a workgroup loops over its tiles.  HHRL_MLP3_WGS=n sets another total (for sweeps).
-static int grid_x(int tiles, int n) {
-  static int total = 0;
+// Workgroups per launch, shared among the networks of the group; a workgroup loops over its tiles.  The backward
+// kernel and the forward kernel that also forms the input gradient hold one workgroup per CU (registers): as many
+// as fill the chip once, 256.  The plain forward kernel fits twice (110 registers, 57 KB of LDS), and two workgroups
+// per CU hide each other's prologue and barriers: 512.  The tiles are dealt evenly: with `per` workgroups allowed
+// per network a workgroup takes ceil(tiles / per) tiles, and only as many workgroups are started as that takes
+// (256 tiles on 85 workgroups would leave one of them a fourth tile while the rest have three).
+// HHRL_MLP3_WGS / HHRL_MLP3_FWD_WGS set other totals (for sweeps).
+static int grid_x(int tiles, int n, bool plain_forward = false) {
+  static int total = 0, total_fwd = 0;
   if (total == 0) {
     const char* e = getenv("HHRL_MLP3_WGS");
     total = (e && atoi(e) > 0) ? atoi(e) : 256;
+    const char* f = getenv("HHRL_MLP3_FWD_WGS");
+    total_fwd = (f && atoi(f) > 0) ? atoi(f) : 2 * total;
   }
-  int per = total / n;
+  int per = (plain_forward ? total_fwd : total) / n;
   if (per < 1) per = 1;
-  return tiles < per ? tiles : per;
+  const int rounds = ceil_div(tiles, per);
+  return ceil_div(tiles, rounds);
 }
 
 // Fewest workgroups per network from which the slab hand-over is used (when the caller gave a slab)
@@ -736,11 +744,12 @@ int hhrl_mlp3_forward_group(const hhrl_mlp3_desc* d, int n, int M, void* stream)
     dx = dx || d[i].forward_dx != 0;
   }
   const int tiles = ceil_div(M, ROWS);
+  const int gxf = grid_x(tiles, n, !dx);
   ProfScope ps("mlp3_forward_kernel", st, flops, 0.0);
   if (dx)
-    hipLaunchKernelGGL(mlp3_forward_kernel<true>, dim3(grid_x(tiles, n), n), dim3(NT), 0, st, grp, M, tiles);
+    hipLaunchKernelGGL(mlp3_forward_kernel<true>, dim3(gxf, n), dim3(NT), 0, st, grp, M, tiles);
   else
-    hipLaunchKernelGGL(mlp3_forward_kernel<false>, dim3(grid_x(tiles, n), n), dim3(NT), 0, st, grp, M, tiles);
+    hipLaunchKernelGGL(mlp3_forward_kernel<false>, dim3(gxf, n), dim3(NT), 0, st, grp, M, tiles);
   return launch_status("mlp3_forward_kernel");
 }
 
