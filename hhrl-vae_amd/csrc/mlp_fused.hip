@@ -67,7 +67,8 @@ __host__ __device__ inline int slab_w3(int K0, int) { return H * K0 + 2 * H + H 
 __host__ __device__ inline int slab_b3(int K0, int N3) { return H * K0 + 2 * H + H * H + N3 * H; }
 // a slab row ends with one more entry, the workgroup's share of the loss (read only when the network forms one)
 __host__ __device__ inline int slab_loss(int K0, int N3) { return H * K0 + 2 * H + H * H + N3 * H + N3; }
-__host__ __device__ inline int slab_floats(int K0, int N3) { return slab_loss(K0, N3) + 1; }
+// (row length: a multiple of four floats, so that rows can be read 16 bytes at a time)
+__host__ __device__ inline int slab_floats(int K0, int N3) { return (slab_loss(K0, N3) + 1 + 3) & ~3; }
 struct NetGroup { Net in[kMaxNets]; };
 
 // LDS map (floats).  Row strides are 4 mod 32 banks and a multiple of four floats: 16-byte reads of a row
@@ -573,22 +574,24 @@ struct AdamRide {
   float tau, om;
 };
 
-// Sum of the slab rows in workgroup order, added to the gradient buffers.  A workgroup owns 32 consecutive
-// parameters; its eight groups of 32 threads each sum every eighth row (eight loads in flight per thread),
-// the eight sums meet in LDS and are added in group order.  blockIdx.y = network.
+// Sum of the slab rows in workgroup order, added to the gradient buffers.  A workgroup owns 64 consecutive
+// parameters; its sixteen groups of 16 threads each sum every sixteenth row, 16 bytes per thread and row (256
+// contiguous bytes per group and row, eight loads in flight per thread), the sixteen sums meet in LDS and are added in
+// group order by the workgroup's first 64 threads, one parameter each.  blockIdx.y = network.
 // ADAM: the thread that completes a gradient element also applies the Adam step to its parameter (and moves the
 // target network's copy): the element's parameter and moments are requested before the slab rows, so they are
 // there when the sum is, and the optimizer takes no launch and no pass of its own.
 template <bool ADAM>
 __global__ __launch_bounds__(256) void mlp3_slab_reduce_kernel(NetGroup grp, int rows, AdamRide ar) {
-  __shared__ float part[8][33];
+  __shared__ float part[16][65];
   const Net& g = grp.in[blockIdx.y];
   if (g.slab == nullptr || g.gw1 == nullptr) return;
   const int K0 = g.K0, N3 = g.N3;
-  const int P = slab_floats(K0, N3);
-  const int c = threadIdx.x & 31, grp8 = threadIdx.x >> 5, e = blockIdx.x * 32 + c;
+  const int P = slab_floats(K0, N3), n_real = slab_loss(K0, N3) + (g.tq1 != nullptr ? 1 : 0);
+  const int c = threadIdx.x & 15, grp16 = threadIdx.x >> 4, e4 = blockIdx.x * 64 + 4 * c;
+  const int e = blockIdx.x * 64 + threadIdx.x;          // the element this thread completes (first 64 threads)
   const bool is_loss = e == slab_loss(K0, N3);          // the row's last entry: a share of the loss, when one is formed
-  const bool last = grp8 == 0 && e < P && !(is_loss && g.tq1 == nullptr);
+  const bool last = threadIdx.x < 64 && e < n_real;
   float* dst = nullptr;
   float g0 = 0.f, p0 = 0.f, m0 = 0.f, v0 = 0.f, t0 = 0.f;
   long off = 0;
@@ -609,25 +612,31 @@ __global__ __launch_bounds__(256) void mlp3_slab_reduce_kernel(NetGroup grp, int
       if (ar.target != nullptr) t0 = ar.target[off];
     }
   }
-  float s = 0.f;
-  if (e < P && !(is_loss && g.tq1 == nullptr)) {
-    const float* p = g.slab + e;
-    int r = grp8;
-    for (; r + 56 < rows; r += 64) {
-      float v[8];
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e4 < P) {                                          // (P is a multiple of four: the 16 bytes lie inside the row)
+    const float* p = g.slab + e4;
+    int r = grp16;
+    for (; r + 112 < rows; r += 128) {
+      float4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = p[(long)(r + 8 * u) * P];
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (long)(r + 16 * u) * P);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) s += v[u];
+      for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
     }
-    for (; r < rows; r += 8) s += p[(long)r * P];
+    for (; r < rows; r += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(p + (long)r * P);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
   }
-  part[grp8][c] = s;
+  part[grp16][4 * c] = s.x;
+  part[grp16][4 * c + 1] = s.y;
+  part[grp16][4 * c + 2] = s.z;
+  part[grp16][4 * c + 3] = s.w;
   __syncthreads();
   if (last) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += part[k][c];
+    for (int k = 0; k < 16; ++k) t += part[k][threadIdx.x];
     const float gn = g0 + t;
     *dst = gn;
     if (ADAM && !is_loss) {
@@ -769,6 +778,7 @@ static int mlp3_backward_impl(const hhrl_mlp3_desc* d, int n, int M, const hhrl_
     if (d[i].gslab != nullptr && d[i].gw1 != nullptr && gx >= kSlabMinRows) {
       HHRL_REQUIRE(d[i].gslab_floats >= (long)gx * P, "mlp3_backward: network %d: slab of %ld floats, %ld needed (hhrl_mlp3_slab_floats)",
                    i, d[i].gslab_floats, (long)gx * P);
+      HHRL_REQUIRE(aligned16(d[i].gslab), "mlp3_backward: network %d: the slab must be 16-byte aligned", i);
       grp.in[i].slab = d[i].gslab;
       ++n_slabs;
       pmax = P > pmax ? P : pmax;
@@ -799,9 +809,9 @@ static int mlp3_backward_impl(const hhrl_mlp3_desc* d, int n, int M, const hhrl_
   if (n_slabs > 0) {
     ProfScope ps("mlp3_slab_reduce_kernel", st, 0.0, 4.0 * n * (double)pmax * (gx + 2 + (fused ? 7 : 0)));
     if (fused)
-      hipLaunchKernelGGL(mlp3_slab_reduce_kernel<true>, dim3(ceil_div(pmax, 32), n), dim3(256), 0, st, grp, gx, ar);
+      hipLaunchKernelGGL(mlp3_slab_reduce_kernel<true>, dim3(ceil_div(pmax, 64), n), dim3(256), 0, st, grp, gx, ar);
     else
-      hipLaunchKernelGGL(mlp3_slab_reduce_kernel<false>, dim3(ceil_div(pmax, 32), n), dim3(256), 0, st, grp, gx, ar);
+      hipLaunchKernelGGL(mlp3_slab_reduce_kernel<false>, dim3(ceil_div(pmax, 64), n), dim3(256), 0, st, grp, gx, ar);
     HHRL_TRY(launch_status("mlp3_slab_reduce_kernel"));
   }
   if (ride != nullptr && !fused) {

@@ -296,7 +296,7 @@ typedef struct {
   /* forward only, optional: nonzero = the launch also writes dx, the input gradient for dL/dy = dy_const on
    * every row (d(-mean Q1)/d(s, a) of a policy step, algorithm.py:1353-1357), and then does not save h1 / h2 */
   int forward_dx;
-  /* backward only, optional: workspace of gslab_floats >= hhrl_mlp3_slab_floats(K0, N3, M) floats.  With it, and with
+  /* backward only, optional: 16-byte aligned workspace of gslab_floats >= hhrl_mlp3_slab_floats(K0, N3, M) floats.  With it, and with
    * enough rows, the workgroups hand their parameter gradients over as slab rows that a second launch sums in a
    * fixed order (same bits on every run) instead of adding them with float atomics. */
   float* gslab; long gslab_floats;
