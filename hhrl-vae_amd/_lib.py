@@ -167,14 +167,15 @@ _hip_rt = None
 ZERO_COPY_MAX_FLOATS = 1 << 16
 
 
-def zero_copy_ok(pinned) -> bool:
+def zero_copy_ok(pinned, any_size: bool = False) -> bool:
     """True when kernels may read and write this pinned host tensor in place, at its host address: the HIP runtime
     reports a device address for it and that address is the host one (unified addressing; torch's pinned memory is
     mapped).  The per-call inference paths then hand their pinned blocks straight to the kernels instead of staging
     them through device buffers (one launch instead of copy + launch + copy).  HHRL_ZERO_COPY=0 turns it off; blocks
-    beyond ZERO_COPY_MAX_FLOATS are staged (a DMA copy moves large blocks faster than a kernel's own reads)."""
+    beyond ZERO_COPY_MAX_FLOATS are staged (a DMA copy moves large blocks faster than a kernel's own reads) unless
+    the caller reads only a small part of the block (any_size)."""
     global _hip_rt
-    if os.environ.get("HHRL_ZERO_COPY") == "0" or pinned.numel() > ZERO_COPY_MAX_FLOATS or not pinned.is_pinned():
+    if os.environ.get("HHRL_ZERO_COPY") == "0" or not pinned.is_pinned() or (pinned.numel() > ZERO_COPY_MAX_FLOATS and not any_size):
         return False
     try:
         if _hip_rt is None:

@@ -512,6 +512,7 @@ class TD3Learner:
         # segment graphs.  Off by default: a collective between two replays is the form every c10d backend supports.
         self.graph_collectives = _os.environ.get("HHRL_DP_GRAPH_COLLECTIVE") == "1" and self._group_backend == "nccl"
         self._seen: Dict[tuple, int] = {}
+        self._slot_graphs: Dict[tuple, int] = {}        # launch chain -> graphs captured so far, one per staging block
         if use_graph not in (True, False, "auto"):
             raise ValueError("use_graph must be True, False or 'auto'")
         self.use_graph = use_graph
@@ -557,11 +558,10 @@ class TD3Learner:
         the Adam steps -- sits in ONE device block that is refreshed by ONE transfer from a ring of pinned
         host buffers (a slot is reused only after the transfer that read it has completed)."""
 
-        RING = 4
-
         def __init__(self, fam: Family, B: int, dev, n_opt: int):
             a64 = lambda n: (n + 63) & ~63
             W = fam.row_width
+            self.B, self.a_dims = B, tuple(fam.a_dims)
             self.n_rows = B * W
             off = a64(self.n_rows)
             self.noise_off = []
@@ -580,20 +580,47 @@ class TD3Learner:
             self.noise = [self.d_in[o:o + B * a].view(B, a) for o, a in zip(self.noise_off, fam.a_dims)]
             self.hyper = [self.d_in[o:o + 8] for o in self.hyper_off]
             self.idx = self.d_in[self.idx_off:self.idx_off + B].view(torch.int32)
-            self.h_in = [torch.zeros(off, dtype=torch.float32).pin_memory() for _ in range(self.RING)]
-            self.h_np = [t.numpy() for t in self.h_in]
-            self.h_idx = [t[self.idx_off:self.idx_off + B].view(torch.int32).numpy() for t in self.h_in]
-            self.events: List[Optional["torch.cuda.Event"]] = [None] * self.RING
-            self.turn = 0
+            self.rings: Dict[tuple, "TD3Learner._Ring"] = {}
+            self.upload = None                 # (pinned source, device destination, floats) when the update fetches its block itself
             self.pi = [ops.dev_empty(B, a, device=dev) for a in fam.a_dims]
             self.y = ops.dev_empty(B, 1, device=dev)
 
-        def next_slot(self):
-            slot = self.turn % self.RING
+        def ring(self, key: tuple) -> "TD3Learner._Ring":
+            r = self.rings.get(key)
+            if r is None:
+                r = self.rings[key] = TD3Learner._Ring(self)
+            return r
+
+    class _Ring:
+        """The pinned staging blocks of ONE launch chain: the host fills one while the device reads the other.  A chain
+        has blocks of its own because its captured graph names them: the graph's first node fetches the block."""
+        SLOTS = 2
+
+        def __init__(self, st: "TD3Learner._Static"):
+            B = st.B
+            self.h_in = [torch.zeros(st.total, dtype=torch.float32).pin_memory() for _ in range(self.SLOTS)]
+            self.h_np = [t.numpy() for t in self.h_in]
+            self.h_ptr = [t.data_ptr() for t in self.h_in]
+            self.h_idx = [t[st.idx_off:st.idx_off + B].view(torch.int32).numpy() for t in self.h_in]
+            self.h_noise = [[h[o:o + B * a].reshape(B, a) for o, a in zip(st.noise_off, st.a_dims)] for h in self.h_np]
+            self.h_hyper = [[h[o:o + 8] for o in st.hyper_off] for h in self.h_np]
+            self.zero_copy = all(_lib.zero_copy_ok(t, any_size=True) for t in self.h_in)      # kernels may read the blocks in place
+            self.events: List[Optional["torch.cuda.Event"]] = [None] * self.SLOTS
+            self.turn = 0
+
+        def next_slot(self) -> int:
+            slot = self.turn % self.SLOTS
             self.turn += 1
             if self.events[slot] is not None:
                 self.events[slot].synchronize()
             return slot
+
+        def release_after(self, slot: int, stream) -> None:
+            """The slot may be refilled once the work enqueued on `stream` so far has run."""
+            ev = self.events[slot]
+            if ev is None:
+                ev = self.events[slot] = torch.cuda.Event()
+            ev.record(stream)
 
     def learn_rows(self, rows, noise: Optional[Sequence] = None, order: Optional[Sequence[int]] = None,
                    _indices=None, global_batch: Optional[int] = None) -> None:
@@ -637,41 +664,54 @@ class TD3Learner:
         else:
             order = ()
         # ---- one pinned block: rows | noise | scalars of the Adam steps this update will take
-        slot = st.next_slot()
-        h = st.h_np[slot]
+        global_batch = int(global_batch) if global_batch is not None else B * self.world_size
+        if global_batch < B:
+            raise ValueError("global_batch %d is smaller than this rank's %d rows" % (global_batch, B))
+        key = (B, policy, order, gather, global_batch)
+        ring = st.ring(key)
+        slot = ring.next_slot()
+        h = ring.h_np[slot]
         rows_on_device = gather or (isinstance(rows, torch.Tensor) and rows.is_cuda)
         if gather:
-            st.h_idx[slot][:] = _indices
+            ring.h_idx[slot][:] = _indices
         elif not rows_on_device:
             h[:st.n_rows].reshape(B, W)[:] = rows.numpy() if isinstance(rows, torch.Tensor) else rows
-        for k, (o, a) in enumerate(zip(st.noise_off, fam.a_dims)):
-            dst = h[o:o + B * a].reshape(B, a)
+        for k, a in enumerate(fam.a_dims):
+            dst = ring.h_noise[slot][k]
             if noise is None:
-                dst[:] = self._np_rng.standard_normal((B, a), dtype=np.float32)
+                self._np_rng.standard_normal(dtype=np.float32, out=dst)        # the draws of standard_normal((B, a)), in place
             else:
                 src = noise[k].detach().cpu().numpy() if isinstance(noise[k], torch.Tensor) else np.asarray(noise[k])
                 if tuple(src.shape) != (B, a):
                     raise ValueError("noise must be [%d, %d], got %s" % (B, a, tuple(src.shape)))
                 dst[:] = src
-        h[st.hyper_off[0]:st.hyper_off[0] + 8] = self.critic.opt.next_step_scalars()
+        hyper = ring.h_hyper[slot]
+        hyper[0][:] = self.critic.opt.next_step_scalars()
         if policy:
             for j, a in enumerate(self.actors):
-                h[st.hyper_off[1 + j]:st.hyper_off[1 + j] + 8] = a.opt.next_step_scalars()
-        if rows_on_device:
-            if not gather:
-                st.rows.copy_(rows)
-            st.d_in[st.n_rows:].copy_(st.h_in[slot][st.n_rows:], non_blocking=True)
+                hyper[1 + j][:] = a.opt.next_step_scalars()
+        if rows_on_device and not gather:
+            st.rows.copy_(rows)
+        lo = st.n_rows if rows_on_device else 0             # rows already on the device: noise, scalars and row numbers only
+        n_up = st.total - lo
+        # A small block is fetched by the update itself: a copy kernel that reads the pinned block in place is the first
+        # launch of the chain (the first node of its graph; one graph per block).  A transfer enqueued between two
+        # replays costs the device 14 us per update (WorkerTD3 at batch 4096: 95.8 -> 82.0 us; the stream hands over to
+        # the copy engine and back, or, with a copy kernel on the stream, from one replay to a plain dispatch and on to
+        # the next replay).  Large blocks (rows gathered on the host) keep the DMA transfer.
+        in_body = (self.group is None and self.use_graph is True and ring.zero_copy and n_up <= _lib.ZERO_COPY_MAX_FLOATS)
+        stream = _lib.current_stream()
+        if in_body:
+            st.upload = (ring.h_ptr[slot] + 4 * lo, P(st.d_in, lo), n_up, slot)
         else:
-            st.d_in.copy_(st.h_in[slot], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(_lib.current_stream())
-        st.events[slot] = ev
+            st.upload = None
+            st.d_in[lo:].copy_(ring.h_in[slot][lo:], non_blocking=True)
+            ring.release_after(slot, stream)
         st.gather = gather                                  # the update starts by gathering its rows on the device
-        st.global_batch = int(global_batch) if global_batch is not None else B * self.world_size
-        if st.global_batch < B:
-            raise ValueError("global_batch %d is smaller than this rank's %d rows" % (st.global_batch, B))
-        key = (B, policy, order, gather, st.global_batch)
+        st.global_batch = global_batch
         self._run_body(key, st, B, policy, order)
+        if in_body:
+            ring.release_after(slot, stream)
         # host-side bookkeeping of what was just enqueued
         self.critic.opt.commit_step()
         self.critic_sched.step()
@@ -687,7 +727,9 @@ class TD3Learner:
         so far; a benchmark warms up until none is "tuning" and every chain it expects has come up."""
         out = {}
         for key in self._seen:
-            if key in self._graphs or key in self._seg_graphs:
+            if key in self._slot_graphs:
+                form = "graph" if self._slot_graphs[key] >= TD3Learner._Ring.SLOTS else "tuning"
+            elif key in self._graphs or key in self._seg_graphs:
                 form = "graph"
             elif self.use_graph is False:
                 form = "eager"
@@ -713,7 +755,9 @@ class TD3Learner:
         0.76 ms eager in a loop, equal within noise when timed one at a time), hence the default."""
         if self.group is not None:
             return self._run_body_group(key, st, B, policy, order)
-        graph = self._graphs.get(key)
+        # (a chain that fetches its own staging block has one graph per block: the block's address is part of the graph)
+        gkey = key if st.upload is None else key + (st.upload[3],)
+        graph = self._graphs.get(gkey)
         mode = self.use_graph
         tune = self._tune.get(key) if mode == "auto" else None
         if mode == "auto" and tune is None:
@@ -730,7 +774,9 @@ class TD3Learner:
             torch.cuda.synchronize()
             with torch.cuda.graph(graph):
                 self._update_body(st, B, policy, order)
-            self._graphs[key] = graph
+            self._graphs[gkey] = graph
+            if gkey is not key:
+                self._slot_graphs[key] = self._slot_graphs.get(key, 0) + 1
             if timed:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -837,6 +883,10 @@ class TD3Learner:
         next_goal = R(self.col_next_goal) if fam.goal_dim else None
         obs = [(R(c), W) for c in self.col_obs]
         next_obs = [(R(c), W) for c in self.col_next_obs]
+
+        if st.upload is not None:                   # this update's staging block: rows | noise | Adam scalars | row numbers
+            src, dst, n_up, _ = st.upload
+            ops.copy2d(src, n_up, dst, n_up, 1, n_up)
 
         # -- target value (no gradient): algorithm.py:1329-1337 / 785-796
         ct, cw_t = self.critic_target, self.critic_target.work(B)
