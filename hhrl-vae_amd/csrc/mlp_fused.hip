@@ -673,8 +673,10 @@ static int grid_x(int tiles, int n, bool plain_forward = false) {
   return ceil_div(tiles, rounds);
 }
 
-// Fewest workgroups per network from which the slab hand-over is used (when the caller gave a slab)
-constexpr int kSlabMinRows = 16;
+// Fewest workgroups per network from which the slab hand-over is used (when the caller gave a slab): always.  With few
+// rows the second launch costs what the stand-alone optimizer launch would (the step rides on it), and the gradients are
+// the same bits on every run at every batch size.
+constexpr int kSlabMinRows = 1;
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 

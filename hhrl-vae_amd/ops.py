@@ -103,7 +103,7 @@ class Mlp3:
 
     def slab(self, M: int, device) -> Optional[torch.Tensor]:
         """Workspace that lets the backward call sum its workgroups' parameter gradients in a fixed order
-        instead of adding them with atomics (None where the atomics path serves M rows)."""
+        instead of adding them with atomics."""
         if M not in self._slabs:
             n = _lib.load().hhrl_mlp3_slab_floats(self.K0, self.N3, M)
             self._slabs[M] = dev_empty(n, device=device) if n > 0 else None

@@ -296,9 +296,9 @@ typedef struct {
   /* forward only, optional: nonzero = the launch also writes dx, the input gradient for dL/dy = dy_const on
    * every row (d(-mean Q1)/d(s, a) of a policy step, algorithm.py:1353-1357), and then does not save h1 / h2 */
   int forward_dx;
-  /* backward only, optional: 16-byte aligned workspace of gslab_floats >= hhrl_mlp3_slab_floats(K0, N3, M) floats.  With it, and with
-   * enough rows, the workgroups hand their parameter gradients over as slab rows that a second launch sums in a
-   * fixed order (same bits on every run) instead of adding them with float atomics. */
+  /* backward only, optional: 16-byte aligned workspace of gslab_floats >= hhrl_mlp3_slab_floats(K0, N3, M) floats.
+   * With it the workgroups hand their parameter gradients over as slab rows that a second launch sums in a fixed
+   * order (same bits on every run) instead of adding them with float atomics. */
   float* gslab; long gslab_floats;
   /* backward only, optional (mse_q1t non-null; N3 = 1, y given, dy null): the network is a critic head whose loss is the
    * TD3 critic loss (algorithm.py:1329-1345 / 785-803).  The launch forms dL/dy itself, as hhrl_td3_target_mse does:
@@ -309,7 +309,7 @@ typedef struct {
   float* mse_loss; float* mse_target;
 } hhrl_mlp3_desc;
 int hhrl_mlp3_supported(int K0, int H1, int H2, int N3);
-long hhrl_mlp3_slab_floats(int K0, int N3, int M);   /* 0: the atomics path serves this M */
+long hhrl_mlp3_slab_floats(int K0, int N3, int M);   /* size of that workspace for M rows */
 int hhrl_mlp3_forward_group(const hhrl_mlp3_desc* nets, int n, int M, void* stream);
 int hhrl_mlp3_backward_group(const hhrl_mlp3_desc* nets, int n, int M, void* stream);
 /* hhrl_mlp3_backward_group followed by the optimizer step of the group's networks: `*_optimizer.step()` right

@@ -406,7 +406,7 @@ def test_td3_target_mse_equals_two_launches(env, B):
 def test_mlp3_backward_td3_target_equals_two_calls(env, M):
     """The backward launch of two critic heads that forms the TD3 target, both losses and dL/dQ itself (mse_* fields)
     against hhrl_td3_target_mse followed by the plain backward launch: the same target, the same bits in every
-    parameter gradient with slabs (M >= 256; float atomics below add in an order of their own), the same losses."""
+    parameter gradient (the slab rows are summed in a fixed order whatever the batch), the same losses."""
     lib, L, dev = env
     K0, n = 11, 2
     g = torch.Generator().manual_seed(77 + M)
@@ -457,10 +457,7 @@ def test_mlp3_backward_td3_target_equals_two_calls(env, M):
     scaled_close("losses", lb.cpu().numpy(), la.cpu().numpy(), rtol=1e-5)
     for i in range(n):
         for k, (a, b) in enumerate(zip(ga[i], gb[i])):
-            if M >= 256:
-                assert torch.equal(a, b), "gradient %d of head %d" % (k, i)
-            else:
-                scaled_close("gradient %d of head %d" % (k, i), b.cpu().numpy(), a.cpu().numpy(), atol_rel=1e-5)
+            assert torch.equal(a, b), "gradient %d of head %d" % (k, i)
     # the form is refused for a wider output or together with a dy
     descs[0].dy, descs[0].lddy = dq[0].data_ptr(), 1
     assert lib.hhrl_mlp3_backward_group(descs, n, M, st) != 0 and b"TD3 target" in lib.hhrl_last_error()
@@ -470,8 +467,8 @@ def test_mlp3_backward_td3_target_equals_two_calls(env, M):
 def test_mlp3_backward_group_adam_equals_two_calls(env, M, polyak):
     """hhrl_mlp3_backward_group_adam against hhrl_mlp3_backward_group followed by hhrl_adam_step_dev /
     hhrl_adam_polyak_step_dev on flat buffers that hold two networks (the two heads of a critic): the same bits in
-    the gradients, parameters, both moments and the target copy, whether the step rides on the slab sum (M >= 256)
-    or follows as a launch of its own (M = 64); padding between the tensors is left alone."""
+    the gradients, parameters, both moments and the target copy (the step rides on the slab sum; without slabs it
+    would follow as a launch of its own); padding between the tensors is left alone."""
     lib, L, dev = env
     K0, N3, n = 11, 1, 2
     g = torch.Generator().manual_seed(1000 + M)
@@ -528,16 +525,11 @@ def test_mlp3_backward_group_adam_equals_two_calls(env, M, polyak):
     for o, sz in zip(offs, sizes * n):
         covered[o: o + sz] = True
     for name, a, b in zip(names, results[0], results[1]):
-        if M >= 256:
-            # slab sums are the same bits on every run; outside the tensors the riding step touches nothing, the
-            # stand-alone one moves padding by its (nonzero, random here) moments
-            assert torch.equal(a[covered], b[covered]), name
-        else:
-            # float atomics add the workgroups' shares in an order that differs between runs
-            assert torch.allclose(a[covered], b[covered], rtol=1e-4, atol=1e-6), name
+        # slab sums are the same bits on every run; outside the tensors the riding step touches nothing, the
+        # stand-alone one moves padding by its (nonzero, random here) moments
+        assert torch.equal(a[covered], b[covered]), name
     assert not torch.equal(results[1][1], p0) and (polyak != torch.equal(results[1][4], t0))
-    if M >= 256:
-        assert torch.equal(results[1][1][~covered], p0[~covered])
+    assert torch.equal(results[1][1][~covered], p0[~covered])
     # a gradient tensor outside the flat buffer is refused
     ride = L.AdamRide(gr.data_ptr() + 4 * 64, p.data_ptr(), m.data_ptr(), v.data_ptr(), total - 64, hyper.data_ptr(), None, 0.0)
     assert lib.hhrl_mlp3_backward_group_adam(descs, n, M, C.byref(ride), st) != 0
@@ -807,7 +799,7 @@ def test_mlp3_fused_matches_torch(env, M, K0, N3, act3):
         d.gw1, d.gb1, d.gw2, d.gb2, d.gw3, d.gb3 = [t.data_ptr() for t in gd]
         d.dx, d.lddx = dxd.data_ptr(), K0 + 1
         n_slab = lib.hhrl_mlp3_slab_floats(K0, N3, M)
-        assert (n_slab > 0) == (M >= 256)
+        assert n_slab > 0
         slab = torch.full((max(n_slab, 1),), float("nan"), device=dev)    # every slab entry read is one the kernel wrote
         if n_slab:
             d.gslab, d.gslab_floats = slab.data_ptr(), n_slab
@@ -832,7 +824,7 @@ def test_mlp3_fused_matches_torch(env, M, K0, N3, act3):
         assert torch.all(dxd[:, K0:] == 0.0)
         for k, (got, want) in enumerate(zip(gd, gws)):
             scaled_close("grad[%d][%d]" % (i, k), got.cpu().numpy(), want.numpy(), atol_rel=1e-5)
-    if M >= 256:
+    if n_slab:
         # parameter gradients handed over through slabs are summed in a fixed order: the same bits on every run,
         # and close to what the atomics path (no slab given) adds up
         first = [[t.clone() for t in keep[i][3]] for i in range(n)]
