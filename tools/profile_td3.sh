@@ -14,9 +14,12 @@ for cfg in "worker 64" "worker 4096" "triple 64" "triple 1024"; do
   mkdir -p $out
   timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 tools/td3_trace.py $1 $2 $updates > $out/line.json
   cat $out/line.json
+  find $out/trace -name "*_kernel_trace.csv" -delete        # the per-dispatch rows (tens of MB); the stats file is what is kept
+  export TD3_TRACE_BRIEF=1                                   # counter passes: no half second of clock warm-up, nothing is timed
   timeout -s KILL 180 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 tools/td3_trace.py $1 $2 40 > /dev/null
   timeout -s KILL 180 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 tools/td3_trace.py $1 $2 40 > /dev/null
   timeout -s KILL 180 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $out/mfma -- python3 tools/td3_trace.py $1 $2 40 > /dev/null
+  unset TD3_TRACE_BRIEF
   echo "$1 $2 done"
 done
 echo done
