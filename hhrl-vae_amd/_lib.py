@@ -19,7 +19,7 @@ _L = C.c_long
 _F = C.c_float
 _D = C.c_double
 
-ABI_VERSION = 103            # HHRL_ABI_VERSION of include/hhrl_hip.h
+ABI_VERSION = 104            # HHRL_ABI_VERSION of include/hhrl_hip.h
 
 
 class LstmDesc(C.Structure):

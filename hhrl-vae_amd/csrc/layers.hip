@@ -172,23 +172,53 @@ __global__ void copy2d_group_kernel(CopyGroup grp, int M) {
 
 // copy2d_group_kernel whose copies may read row idx[r] of their source instead of row r: the minibatch gather out of
 // a device-resident replay buffer and every copy of replay columns into a network input as ONE launch (the copies then
-// read the replay buffer directly instead of waiting for the gathered rows).
+// read the replay buffer directly instead of waiting for the gathered rows).  A workgroup takes a tile of consecutive
+// rows of one block (blockIdx.y) and reads the tile's row numbers ONCE, into LDS: they may lie in pinned host memory
+// (the update's staging block, read in place), where every read is a trip over the host link.  gather == 2: a flat
+// copy of C floats (the staging block itself on its way into device memory), dealt over the workgroups like a zero fill.
 struct GCopyInst { const float* in; float* out; long ldi; int ldo, C, gather; };
 struct GCopyGroup { GCopyInst in[HHRL_COPY_GROUP_MAX]; };
-__global__ void gather_copy_group_kernel(GCopyGroup grp, int M, const int* __restrict__ idx, int n_in) {
+constexpr int kGcElems = 1024;      // elements per workgroup and row-copy tile, about
+constexpr int kGcMaxRows = 64;
+__host__ __device__ inline int gc_tile_rows(int C) {
+  const int r = kGcElems / C;
+  return r < 1 ? 1 : (r > kGcMaxRows ? kGcMaxRows : r);
+}
+__global__ __launch_bounds__(256) void gather_copy_group_kernel(GCopyGroup grp, int M, const int* __restrict__ idx, int n_in) {
+  __shared__ int sidx[kGcMaxRows];
   const GCopyInst& g = grp.in[blockIdx.y];
-  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g.in == nullptr) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (4 * e + u < g.C) g.out[4 * e + u] = 0.f;
+  const int tid = threadIdx.x, C = g.C;
+  if (g.in == nullptr || g.gather == 2) {             // flat: C floats, an equal run of whole 16-byte groups per workgroup
+    const long quads = ((long)C + 3) / 4, per = (quads + gridDim.x - 1) / gridDim.x;
+    const long lo = 4 * per * blockIdx.x, hi = lo + 4 * per < C ? lo + 4 * per : C;
+    if (g.in == nullptr) {
+      for (long i = lo + tid; i < hi; i += 256) g.out[i] = 0.f;
+    } else {
+      for (long i = lo + tid; i < hi; i += 256) g.out[i] = g.in[i];
+    }
     return;
   }
-  if (e >= (long)M * g.C) return;
-  const int c = e % g.C;
-  const long r = e / g.C;
-  const long src = g.gather ? (long)min(max(idx[r], 0), n_in - 1) : r;      // an index outside the buffer cannot leave it
-  g.out[r * g.ldo + c] = g.in[src * g.ldi + c];
+  const int R = gc_tile_rows(C), row0 = blockIdx.x * R;
+  if (row0 >= M) return;
+  if (g.gather) {
+    if (tid < R && row0 + tid < M) sidx[tid] = min(max(idx[row0 + tid], 0), n_in - 1);   // an index outside the buffer cannot leave it
+    __syncthreads();
+  }
+  const int n = min(R, M - row0) * C;
+  for (int base = 0; base < n; base += 4 * 256) {      // four loads in flight per thread
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = min(base + u * 256 + tid, n - 1), rr = e / C, c = e - rr * C;
+      const long src = g.gather ? (long)sidx[rr] : (long)(row0 + rr);
+      v[u] = g.in[src * g.ldi + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = base + u * 256 + tid, rr = e / C, c = e - rr * C;
+      if (e < n) g.out[(long)(row0 + rr) * g.ldo + c] = v[u];
+    }
+  }
 }
 
 __global__ void fill_kernel(float* p, long n, float v) {
@@ -515,27 +545,28 @@ int hhrl_gather_copy_group(const hhrl_gcopy_desc* d, int n, int M, const int* id
   HHRL_REQUIRE(d && n >= 1 && n <= HHRL_COPY_GROUP_MAX, "gather_copy_group: %d blocks (1..%d supported)", n, HHRL_COPY_GROUP_MAX);
   HHRL_REQUIRE(M > 0, "gather_copy_group: M=%d", M);
   GCopyGroup g;
-  long threads = 0;
+  long wgs = 1;
   double bytes = 0.0;
   for (int i = 0; i < n; ++i) {
     HHRL_REQUIRE(d[i].out, "gather_copy_group: block %d: null pointer", i);
     HHRL_REQUIRE(d[i].C > 0, "gather_copy_group: block %d: C=%d", i, d[i].C);
+    HHRL_REQUIRE(d[i].gather >= 0 && d[i].gather <= 2, "gather_copy_group: block %d: gather=%d", i, d[i].gather);
     long need;
-    if (d[i].in) {
+    if (d[i].in && d[i].gather != 2) {
       HHRL_REQUIRE(d[i].ldi >= d[i].C && d[i].ldo >= d[i].C, "gather_copy_group: block %d: bad shape C=%d ldi=%ld ldo=%d", i, d[i].C,
                    d[i].ldi, d[i].ldo);
       HHRL_REQUIRE(!d[i].gather || (idx && n_in > 0), "gather_copy_group: block %d gathers, but there are no row numbers", i);
-      need = (long)M * d[i].C;
+      need = ceil_div(M, gc_tile_rows(d[i].C));
       bytes += 8.0 * M * d[i].C;
     } else {
-      need = ((long)d[i].C + 3) / 4;
-      bytes += 4.0 * d[i].C;
+      need = ceil_div(((long)d[i].C + 3) / 4, 256);           // four floats per thread
+      bytes += (d[i].in ? 8.0 : 4.0) * d[i].C;
     }
     g.in[i] = GCopyInst{d[i].in, d[i].out, d[i].ldi, d[i].ldo, d[i].C, d[i].gather};
-    threads = need > threads ? need : threads;
+    wgs = need > wgs ? need : wgs;
   }
   ProfScope ps("gather_copy_group_kernel", as_stream(stream), 0.0, bytes);
-  hipLaunchKernelGGL(gather_copy_group_kernel, dim3(ceil_div(threads, 256), n), dim3(256), 0, as_stream(stream), g, M, idx, n_in);
+  hipLaunchKernelGGL(gather_copy_group_kernel, dim3((unsigned)wgs, n), dim3(256), 0, as_stream(stream), g, M, idx, n_in);
   return launch_status("gather_copy_group_kernel");
 }
 

@@ -239,16 +239,30 @@ def copy2d(inp: int, ldi: int, out: int, ldo: int, M: int, Cc: int) -> None:
 class CopyQueue:
     """Collects [M, C] block copies that do not depend on each other and issues them as one launch."""
 
-    def __init__(self, M: int, gather=None):
+    def __init__(self, M: int, gather=None, fetch=None):
         """gather = (rows_ptr, row_width, table_ptr, n_table_rows, idx_ptr): the [M, row_width] block at rows_ptr is
         itself row idx[r] of a device-resident table.  The queue then fills that block in the same launch, and copies
-        that read a column range of it read the table directly (they do not wait for the gathered rows)."""
+        that read a column range of it read the table directly (they do not wait for the gathered rows).
+        fetch = (pinned_ptr, device_ptr, n_floats): the launch also copies this staging block from pinned host memory
+        into device memory, and whatever the queue reads out of the block's device copy (sources, row numbers) it
+        reads from the pinned block instead -- the device copy is being written by this very launch."""
         self.M = M
         self.items = []
         self.gather = gather
+        self.fetch = fetch
+        if fetch is not None:
+            self.items.append((fetch[0], 0, fetch[1], 0, fetch[2], 2))
         if gather is not None:
             rows, W, table, n_in, idx = gather
             self.items.append((table, W, rows, W, W, 1))
+
+    def _pinned(self, p: int) -> int:
+        """Address p, or its counterpart in the pinned block when p lies in the block's device copy."""
+        if self.fetch is not None:
+            src, dst, n = self.fetch
+            if dst <= p < dst + 4 * n:
+                return p - dst + src
+        return p
 
     def add(self, inp: int, ldi: int, out: int, ldo: int, Cc: int) -> None:
         if self.gather is not None:
@@ -257,7 +271,7 @@ class CopyQueue:
             if ldi == W and 0 <= off and off + 4 * Cc <= 4 * W:      # a column range of the gathered rows
                 self.items.append((table + off, W, out, ldo, Cc, 1))
                 return
-        self.items.append((inp, ldi, out, ldo, Cc, 0))
+        self.items.append((self._pinned(inp), ldi, out, ldo, Cc, 0))
 
     def add_zero(self, out: int, n: int) -> None:
         """n floats at `out` set to zero in the same launch (a gradient buffer's zero_grad)."""
@@ -267,11 +281,12 @@ class CopyQueue:
         lib = _lib.load()
         for i in range(0, len(self.items), _lib.COPY_GROUP_MAX):
             part = self.items[i:i + _lib.COPY_GROUP_MAX]
-            if self.gather is not None:
+            if self.gather is not None or self.fetch is not None:
                 arr = (_lib.GCopyDesc * len(part))()
                 for d, (inp, ldi, out, ldo, Cc, ga) in zip(arr, part):
                     d.inp, d.ldi, d.out, d.ldo, d.C, d.gather = inp, ldi, out, ldo, Cc, ga
-                check(lib.hhrl_gather_copy_group(arr, len(part), self.M, self.gather[4], self.gather[3], _lib.stream_ptr()))
+                idx, n_in = (self._pinned(self.gather[4]), self.gather[3]) if self.gather is not None else (None, 0)
+                check(lib.hhrl_gather_copy_group(arr, len(part), self.M, idx, n_in, _lib.stream_ptr()))
                 continue
             arr = (_lib.CopyDesc * len(part))()
             for d, (inp, ldi, out, ldo, Cc, _) in zip(arr, part):

@@ -884,10 +884,6 @@ class TD3Learner:
         obs = [(R(c), W) for c in self.col_obs]
         next_obs = [(R(c), W) for c in self.col_next_obs]
 
-        if st.upload is not None:                   # this update's staging block: rows | noise | Adam scalars | row numbers
-            src, dst, n_up, _ = st.upload
-            ops.copy2d(src, n_up, dst, n_up, 1, n_up)
-
         # -- target value (no gradient): algorithm.py:1329-1337 / 785-796
         ct, cw_t = self.critic_target, self.critic_target.work(B)
 
@@ -901,7 +897,10 @@ class TD3Learner:
         items += [c.feature_item(k, B, obs[k][0], W) for k in range(n_str)]
         # every piece of a network input that is a plain column range of the sampled rows: one launch -- with a
         # device-resident replay buffer the launch that gathers the rows themselves (the copies read the buffer)
-        cq = ops.CopyQueue(B, (P(rows), W, P(self._dev_mem), self.memory_capacity, st.idx.data_ptr()) if gather else None)
+        # ... and, where the update fetches its own staging block (rows | noise | Adam scalars | row numbers, st.upload),
+        # the launch that copies the block out of pinned host memory: the first node of the update's graph
+        cq = ops.CopyQueue(B, (P(rows), W, P(self._dev_mem), self.memory_capacity, st.idx.data_ptr()) if gather else None,
+                           fetch=st.upload[:3] if st.upload is not None else None)
         for k, a in enumerate(self.actor_targets):
             a.stage_inputs(cq, B, next_obs[k][0], W, next_goal, W)
         ct.stage_inputs(cq, B, next_obs, next_goal, W)

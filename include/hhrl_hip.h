@@ -37,7 +37,7 @@ extern "C" {
 /* The ABI version this header describes; hhrl_version() returns the one the library was built with.  A binding checks
  * that they agree before it passes descriptor structs (their layout is part of the ABI).
  * 101: hhrl_lstm_desc gained `no_backward`; hhrl_gather_copy_group, hhrl_randn_fill, hhrl_vae_learn_steps added. */
-#define HHRL_ABI_VERSION 103
+#define HHRL_ABI_VERSION 104
 int hhrl_version(void);
 const char* hhrl_last_error(void);
 
@@ -135,7 +135,10 @@ int hhrl_gather_rows(const float* in, long ldi, int n_in, const int* idx, float*
 /* hhrl_copy2d_group whose blocks may gather: a block with gather != 0 reads row idx[r] of its source (in: a column of
  * the replay buffer, ldi: the buffer's row width) instead of row r; row numbers outside [0, n_in) are clamped.  The
  * minibatch gather of hhrl_gather_rows, every torch.cat piece that is a column range of the sampled rows and the
- * zero_grad fills of an update as ONE launch (algorithm.py:287, 483, 772, 1320 and the lines cited above). */
+ * zero_grad fills of an update as ONE launch (algorithm.py:287, 483, 772, 1320 and the lines cited above).
+ * gather == 2: a flat copy of C floats from in to out (ldi, ldo and M do not apply), e.g. a caller's pinned staging
+ * block on its way into device memory in the same launch.  `idx` and the sources may lie in pinned host memory that
+ * the device can address: the row numbers are read once per tile of rows. */
 typedef struct { const float* in; long ldi; float* out; int ldo; int C; int gather; } hhrl_gcopy_desc;
 int hhrl_gather_copy_group(const hhrl_gcopy_desc* blocks, int n, int M, const int* idx, int n_in, void* stream);
 /* p[i] = value */
