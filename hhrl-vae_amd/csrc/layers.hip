@@ -170,6 +170,46 @@ __global__ void copy2d_group_kernel(CopyGroup grp, int M) {
   g.out[r * g.ldo + c] = g.in[r * g.ldi + c];
 }
 
+// Standard normals from a counter-based generator: Philox4x32-10 (Salmon et al., SC'11) keyed by the seed, counter =
+// index of the output quadruple, four uniforms per counter turned into four normals by two Box-Muller pairs.  Element
+// i of the stream depends on (seed, i) only: a fill of n values at offset o equals the same range of one long fill,
+// whatever the grid, so a pool can be refilled piecewise and a run can be repeated from its seed.
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
+  const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+  const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
+  c[1] = (unsigned)p1;
+  c[3] = (unsigned)p0;
+  c[0] = n0;
+  c[2] = n2;
+}
+__device__ __forceinline__ void philox4x32_10(unsigned long long ctr, unsigned long long seed, unsigned (&out)[4]) {
+  unsigned c[4] = {(unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u};
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out[i] = c[i];
+}
+// (0, 1]: never zero, so the logarithm below is finite
+__device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f); }
+// the four normals of stream quadruple q: two Box-Muller pairs from one Philox block
+__device__ __forceinline__ void normals4(unsigned long long q, unsigned long long seed, float (&z)[4]) {
+  unsigned r[4];
+  philox4x32_10(q, seed, r);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float rad = sqrtf(-2.0f * logf(u01(r[2 * h])));
+    float sn, cs;
+    sincospif(2.0f * u01(r[2 * h + 1]), &sn, &cs);
+    z[2 * h] = rad * cs;
+    z[2 * h + 1] = rad * sn;
+  }
+}
+
 // copy2d_group_kernel whose copies may read row idx[r] of their source instead of row r: the minibatch gather out of
 // a device-resident replay buffer and every copy of replay columns into a network input as ONE launch (the copies then
 // read the replay buffer directly instead of waiting for the gathered rows).  A workgroup takes a tile of consecutive
@@ -188,13 +228,25 @@ __global__ __launch_bounds__(256) void gather_copy_group_kernel(GCopyGroup grp, 
   __shared__ int sidx[kGcMaxRows];
   const GCopyInst& g = grp.in[blockIdx.y];
   const int tid = threadIdx.x, C = g.C;
-  if (g.in == nullptr || g.gather == 2) {             // flat: C floats, an equal run of whole 16-byte groups per workgroup
+  if (g.in == nullptr || g.gather >= 2) {             // flat: C floats, an equal run of whole 16-byte groups per workgroup
     const long quads = ((long)C + 3) / 4, per = (quads + gridDim.x - 1) / gridDim.x;
     const long lo = 4 * per * blockIdx.x, hi = lo + 4 * per < C ? lo + 4 * per : C;
     if (g.in == nullptr) {
       for (long i = lo + tid; i < hi; i += 256) g.out[i] = 0.f;
-    } else {
+    } else if (g.gather == 2) {
       for (long i = lo + tid; i < hi; i += 256) g.out[i] = g.in[i];
+    } else {
+      // standard normals: out[i] = element (offset + i) of the stream of `seed`; the two 64-bit numbers are read from
+      // memory (a replayed launch draws new values when the caller has advanced them); offset is a multiple of four
+      const unsigned long long* so = reinterpret_cast<const unsigned long long*>(g.in);
+      const unsigned long long seed = so[0], q0 = so[1] >> 2;
+      for (long qd = per * blockIdx.x + tid; qd < per * (blockIdx.x + 1) && qd < quads; qd += 256) {
+        float z[4];
+        normals4(q0 + (unsigned long long)qd, seed, z);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (4 * qd + e < C) g.out[4 * qd + e] = z[e];
+      }
     }
     return;
   }
@@ -226,48 +278,13 @@ __global__ void fill_kernel(float* p, long n, float v) {
   if (idx < n) p[idx] = v;
 }
 
-// Standard normals from a counter-based generator: Philox4x32-10 (Salmon et al., SC'11) keyed by the seed, counter =
-// index of the output quadruple, four uniforms per counter turned into four normals by two Box-Muller pairs.  Element
-// i of the stream depends on (seed, i) only: a fill of n values at offset o equals the same range of one long fill,
-// whatever the grid, so a pool can be refilled piecewise and a run can be repeated from its seed.
-__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
-  const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
-  const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
-  c[1] = (unsigned)p1;
-  c[3] = (unsigned)p0;
-  c[0] = n0;
-  c[2] = n2;
-}
-__device__ __forceinline__ void philox4x32_10(unsigned long long ctr, unsigned long long seed, unsigned (&out)[4]) {
-  unsigned c[4] = {(unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u};
-  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    philox_round(c, k0, k1);
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) out[i] = c[i];
-}
-// (0, 1]: never zero, so the logarithm below is finite
-__device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f); }
 __global__ __launch_bounds__(256) void randn_fill_kernel(float* __restrict__ out, long n, unsigned long long seed, unsigned long long offset) {
   // thread t produces elements 4 t' .. 4 t' + 3 of the STREAM (t' counted from the stream's origin) that fall into
   // [offset, offset + n)
   const unsigned long long q0 = offset >> 2;
   const unsigned long long q = q0 + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned r[4];
-  philox4x32_10(q, seed, r);
   float z[4];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const float rad = sqrtf(-2.0f * logf(u01(r[2 * h])));
-    float sn, cs;
-    sincospif(2.0f * u01(r[2 * h + 1]), &sn, &cs);
-    z[2 * h] = rad * cs;
-    z[2 * h + 1] = rad * sn;
-  }
+  normals4(q, seed, z);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const unsigned long long i = 4 * q + e;
@@ -550,9 +567,11 @@ int hhrl_gather_copy_group(const hhrl_gcopy_desc* d, int n, int M, const int* id
   for (int i = 0; i < n; ++i) {
     HHRL_REQUIRE(d[i].out, "gather_copy_group: block %d: null pointer", i);
     HHRL_REQUIRE(d[i].C > 0, "gather_copy_group: block %d: C=%d", i, d[i].C);
-    HHRL_REQUIRE(d[i].gather >= 0 && d[i].gather <= 2, "gather_copy_group: block %d: gather=%d", i, d[i].gather);
+    HHRL_REQUIRE(d[i].gather >= 0 && d[i].gather <= 3, "gather_copy_group: block %d: gather=%d", i, d[i].gather);
+    HHRL_REQUIRE(d[i].gather != 3 || (d[i].in && reinterpret_cast<uintptr_t>(d[i].in) % 8 == 0),
+                 "gather_copy_group: block %d: the seed and offset of a block of normals must be 8-byte aligned", i);
     long need;
-    if (d[i].in && d[i].gather != 2) {
+    if (d[i].in && d[i].gather < 2) {
       HHRL_REQUIRE(d[i].ldi >= d[i].C && d[i].ldo >= d[i].C, "gather_copy_group: block %d: bad shape C=%d ldi=%ld ldo=%d", i, d[i].C,
                    d[i].ldi, d[i].ldo);
       HHRL_REQUIRE(!d[i].gather || (idx && n_in > 0), "gather_copy_group: block %d gathers, but there are no row numbers", i);

@@ -243,23 +243,22 @@ class CopyQueue:
         """gather = (rows_ptr, row_width, table_ptr, n_table_rows, idx_ptr): the [M, row_width] block at rows_ptr is
         itself row idx[r] of a device-resident table.  The queue then fills that block in the same launch, and copies
         that read a column range of it read the table directly (they do not wait for the gathered rows).
-        fetch = (pinned_ptr, device_ptr, n_floats): the launch also copies this staging block from pinned host memory
-        into device memory, and whatever the queue reads out of the block's device copy (sources, row numbers) it
-        reads from the pinned block instead -- the device copy is being written by this very launch."""
+        fetch = ((pinned_ptr, device_ptr, n_floats), ...): the launch also copies these pieces of a staging block from
+        pinned host memory into device memory, and whatever the queue reads out of their device copy (sources, row
+        numbers) it reads from the pinned block instead -- the device copy is being written by this very launch."""
         self.M = M
         self.items = []
         self.gather = gather
         self.fetch = fetch
-        if fetch is not None:
-            self.items.append((fetch[0], 0, fetch[1], 0, fetch[2], 2))
+        for src, dst, n in (fetch or ()):
+            self.items.append((src, 0, dst, 0, n, 2))
         if gather is not None:
             rows, W, table, n_in, idx = gather
             self.items.append((table, W, rows, W, W, 1))
 
     def _pinned(self, p: int) -> int:
         """Address p, or its counterpart in the pinned block when p lies in the block's device copy."""
-        if self.fetch is not None:
-            src, dst, n = self.fetch
+        for src, dst, n in (self.fetch or ()):
             if dst <= p < dst + 4 * n:
                 return p - dst + src
         return p
@@ -272,6 +271,11 @@ class CopyQueue:
                 self.items.append((table + off, W, out, ldo, Cc, 1))
                 return
         self.items.append((self._pinned(inp), ldi, out, ldo, Cc, 0))
+
+    def add_normals(self, out: int, n: int, seed_offset: int) -> None:
+        """n standard normals at `out`: elements offset .. offset + n - 1 of the stream of `seed`, the two 64-bit
+        integers at address `seed_offset` (read by the launch itself: a replay draws what the caller has put there)."""
+        self.items.append((seed_offset, 0, out, 0, n, 3))
 
     def add_zero(self, out: int, n: int) -> None:
         """n floats at `out` set to zero in the same launch (a gradient buffer's zero_grad)."""

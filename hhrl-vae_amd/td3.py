@@ -500,6 +500,8 @@ class TD3Learner:
         # but hold different shards of the global minibatch: each rank's noise stream is offset by its rank, so
         # that the global batch carries independent draws like the single-device update of the same rows would
         self._np_rng = np.random.default_rng((3407 if seed is None else seed) + 1000003 * self.rank)
+        self._noise_seed = (3407 if seed is None else int(seed)) + 1000003 * self.rank      # device draws: the stream's key
+        self._noise_drawn = 0                                                               # ... and how far it has been used
         self._loss = ops.dev_zeros(2, device=dev)
         self._statics: Dict[int, "TD3Learner._Static"] = {}
         self._policy_io: Dict[Tuple[int, int], dict] = {}
@@ -604,6 +606,10 @@ class TD3Learner:
             self.h_idx = [t[st.idx_off:st.idx_off + B].view(torch.int32).numpy() for t in self.h_in]
             self.h_noise = [[h[o:o + B * a].reshape(B, a) for o, a in zip(st.noise_off, st.a_dims)] for h in self.h_np]
             self.h_hyper = [[h[o:o + 8] for o in st.hyper_off] for h in self.h_np]
+            # seed and stream offset of an update that draws its smoothing noise on the device: two 64-bit integers in
+            # the spare part of the first optimizer's scalars
+            self.rng_off = st.hyper_off[0] + 16
+            self.h_rng = [h[self.rng_off:self.rng_off + 4].view(np.uint64) for h in self.h_np]
             self.zero_copy = all(_lib.zero_copy_ok(t, any_size=True) for t in self.h_in)      # kernels may read the blocks in place
             self.events: List[Optional["torch.cuda.Event"]] = [None] * self.SLOTS
             self.turn = 0
@@ -667,7 +673,11 @@ class TD3Learner:
         global_batch = int(global_batch) if global_batch is not None else B * self.world_size
         if global_batch < B:
             raise ValueError("global_batch %d is smaller than this rank's %d rows" % (global_batch, B))
-        key = (B, policy, order, gather, global_batch)
+        # Without noise from the caller, an update that fetches its own staging block (below) draws the noise on the
+        # device, in that same launch, as the reference does (torch.randn_like on the device, algorithm.py:790, 1333):
+        # the stream of hhrl_randn_fill for this learner's seed.  4096 draws cost the host 26 us per update otherwise.
+        on_device = noise is None and self.group is None and self.use_graph is True
+        key = (B, policy, order, gather, global_batch, on_device)
         ring = st.ring(key)
         slot = ring.next_slot()
         h = ring.h_np[slot]
@@ -676,7 +686,13 @@ class TD3Learner:
             ring.h_idx[slot][:] = _indices
         elif not rows_on_device:
             h[:st.n_rows].reshape(B, W)[:] = rows.numpy() if isinstance(rows, torch.Tensor) else rows
+        lo = st.n_rows if rows_on_device else 0             # rows already on the device: noise, scalars and row numbers only
+        n_up = st.total - lo
+        in_body = (self.group is None and self.use_graph is True and ring.zero_copy and n_up <= _lib.ZERO_COPY_MAX_FLOATS)
+        on_device = on_device and in_body
         for k, a in enumerate(fam.a_dims):
+            if on_device:
+                break
             dst = ring.h_noise[slot][k]
             if noise is None:
                 self._np_rng.standard_normal(dtype=np.float32, out=dst)        # the draws of standard_normal((B, a)), in place
@@ -692,17 +708,23 @@ class TD3Learner:
                 hyper[1 + j][:] = a.opt.next_step_scalars()
         if rows_on_device and not gather:
             st.rows.copy_(rows)
-        lo = st.n_rows if rows_on_device else 0             # rows already on the device: noise, scalars and row numbers only
-        n_up = st.total - lo
         # A small block is fetched by the update itself: a copy kernel that reads the pinned block in place is the first
         # launch of the chain (the first node of its graph; one graph per block).  A transfer enqueued between two
         # replays costs the device 14 us per update (WorkerTD3 at batch 4096: 95.8 -> 82.0 us; the stream hands over to
         # the copy engine and back, or, with a copy kernel on the stream, from one replay to a plain dispatch and on to
         # the next replay).  Large blocks (rows gathered on the host) keep the DMA transfer.
-        in_body = (self.group is None and self.use_graph is True and ring.zero_copy and n_up <= _lib.ZERO_COPY_MAX_FLOATS)
         stream = _lib.current_stream()
         if in_body:
-            st.upload = (ring.h_ptr[slot] + 4 * lo, P(st.d_in, lo), n_up, slot)
+            hp, n0, n1 = ring.h_ptr[slot], st.noise_off[0], st.hyper_off[0]
+            if on_device:                                   # everything but the noise, which the launch draws itself
+                ring.h_rng[slot][0], ring.h_rng[slot][1] = self._noise_seed, self._noise_drawn
+                self._noise_drawn += n1 - n0
+                pieces = ((hp + 4 * n1, P(st.d_in, n1), st.total - n1),)
+                if lo < n0:
+                    pieces += ((hp + 4 * lo, P(st.d_in, lo), n0 - lo),)
+                st.upload = (pieces, slot, (P(st.d_in, n0), n1 - n0, hp + 4 * ring.rng_off))
+            else:
+                st.upload = (((hp + 4 * lo, P(st.d_in, lo), n_up),), slot, None)
         else:
             st.upload = None
             st.d_in[lo:].copy_(ring.h_in[slot][lo:], non_blocking=True)
@@ -756,7 +778,7 @@ class TD3Learner:
         if self.group is not None:
             return self._run_body_group(key, st, B, policy, order)
         # (a chain that fetches its own staging block has one graph per block: the block's address is part of the graph)
-        gkey = key if st.upload is None else key + (st.upload[3],)
+        gkey = key if st.upload is None else key + (st.upload[1],)
         graph = self._graphs.get(gkey)
         mode = self.use_graph
         tune = self._tune.get(key) if mode == "auto" else None
@@ -900,7 +922,9 @@ class TD3Learner:
         # ... and, where the update fetches its own staging block (rows | noise | Adam scalars | row numbers, st.upload),
         # the launch that copies the block out of pinned host memory: the first node of the update's graph
         cq = ops.CopyQueue(B, (P(rows), W, P(self._dev_mem), self.memory_capacity, st.idx.data_ptr()) if gather else None,
-                           fetch=st.upload[:3] if st.upload is not None else None)
+                           fetch=st.upload[0] if st.upload is not None else None)
+        if st.upload is not None and st.upload[2] is not None:
+            cq.add_normals(*st.upload[2])                # the smoothing noise of every actor, one run of the stream
         for k, a in enumerate(self.actor_targets):
             a.stage_inputs(cq, B, next_obs[k][0], W, next_goal, W)
         ct.stage_inputs(cq, B, next_obs, next_goal, W)
@@ -1051,7 +1075,9 @@ class TD3Learner:
 
     def _learn(self, indices=None, noise=None, order=None, global_batch=None) -> None:
         if indices is None:
-            indices = np.random.choice(min(self._n_stored(), self.memory_capacity), size=self.batch_size)
+            # np.random.choice(n, size=B) (algorithm.py:286, 482, 771, 1319): with replacement and no weights that IS
+            # randint(0, n, size=B) -- same values, same generator state afterwards -- without 2 us of argument checks
+            indices = np.random.randint(0, min(self._n_stored(), self.memory_capacity), size=self.batch_size)
         if self.device_replay and hasattr(self, "_sync_replay"):
             self._sync_replay()
             self.learn_rows(None, noise, order, _indices=np.asarray(indices), global_batch=global_batch)

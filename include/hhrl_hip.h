@@ -137,8 +137,11 @@ int hhrl_gather_rows(const float* in, long ldi, int n_in, const int* idx, float*
  * minibatch gather of hhrl_gather_rows, every torch.cat piece that is a column range of the sampled rows and the
  * zero_grad fills of an update as ONE launch (algorithm.py:287, 483, 772, 1320 and the lines cited above).
  * gather == 2: a flat copy of C floats from in to out (ldi, ldo and M do not apply), e.g. a caller's pinned staging
- * block on its way into device memory in the same launch.  `idx` and the sources may lie in pinned host memory that
- * the device can address: the row numbers are read once per tile of rows. */
+ * block on its way into device memory in the same launch.  gather == 3: out[0..C) = elements offset .. offset + C - 1
+ * of the standard-normal stream of hhrl_randn_fill, where `in` points at two 64-bit integers {seed, offset} (offset a
+ * multiple of four) that the launch reads from memory: the draws of `torch.randn_like` for the target-policy smoothing
+ * (algorithm.py:790, 1333) inside a replayed launch.  `idx` and the sources may lie in pinned host memory that the
+ * device can address: the row numbers are read once per tile of rows. */
 typedef struct { const float* in; long ldi; float* out; int ldo; int C; int gather; } hhrl_gcopy_desc;
 int hhrl_gather_copy_group(const hhrl_gcopy_desc* blocks, int n, int M, const int* idx, int n_in, void* stream);
 /* p[i] = value */

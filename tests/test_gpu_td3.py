@@ -310,6 +310,47 @@ def test_td3_device_replay_matches_host_gather():
             both_learn()
 
 
+def test_td3_smoothing_noise_drawn_on_the_device():
+    """Without noise from the caller a single-device learner draws the target-policy smoothing noise (algorithm.py:790,
+    1333: torch.randn_like on the device) in the update's first launch: consecutive runs of the standard-normal stream
+    of hhrl_randn_fill for the learner's seed, the same values whether the launch chain runs eagerly (first updates) or
+    is replayed from its graphs; two learners with one seed stay bit-identical, host-gathered and device-resident replay
+    alike."""
+    import ctypes as C
+    import hhrl_vae_amd.algorithm as A
+    from hhrl_vae_amd import _lib as L
+    lib = L.load()
+    for make in ((lambda: A.WorkerTD3(gen.cav_cfg(o=5, g=3, hidden=(16, 12), batch=8, cap=24), seed=11)),
+                 (lambda: A.HATD3Triple(gen.light_cfg(o=(5, 6, 7), T=4, s=8, a=(1, 2, 3), actor_h=(12, 10), critic_h=(14, 12),
+                                                      batch=8, cap=24), seed=11, device_replay=True))):
+        a, b = make(), make()
+        rows = np.random.RandomState(3).uniform(-1, 1, size=(20, a.fam.row_width))
+        for net in (a, b):
+            net.memory[:20] = rows
+            net.pointer = 20
+        n_act = len(a.fam.a_dims)
+        for it in range(14):
+            idx = np.random.RandomState(50 + it).choice(20, size=8)
+            for net in (a, b):
+                net._learn(idx, None, list(range(n_act)))       # one actor order: both chains reach their replayed form
+            st = a._statics[8]
+            n_noise = st.hyper_off[0] - st.noise_off[0]
+            assert a._noise_drawn == (it + 1) * n_noise
+            want = torch.empty(n_noise, device=a.device)
+            L.check(lib.hhrl_randn_fill(want.data_ptr(), n_noise, C.c_ulonglong(a._noise_seed), C.c_ulonglong(it * n_noise),
+                                        L.stream_ptr()))
+            for k, (o, ad) in enumerate(zip(st.noise_off, a.fam.a_dims)):
+                got = st.noise[k].reshape(-1)
+                assert torch.equal(got, want[o - st.noise_off[0]: o - st.noise_off[0] + 8 * ad]), (it, k)
+        assert set(a.launch_forms().values()) == {"graph"}
+        sa, sb = a.state_dicts(), b.state_dicts()
+        for n in sa:
+            for k in sa[n]:
+                assert torch.equal(sa[n][k], sb[n][k]), (n, k)
+        flat = torch.cat([x.reshape(-1) for x in a._statics[8].noise])
+        assert torch.isfinite(flat).all() and flat.abs().max() < 6.0
+
+
 def test_td3_alternating_global_batch_keeps_each_chains_constant():
     """Two global batch sizes alternating at one shard size, on a family that takes the layer-by-layer path
     (the policy step's dL/dQ1 = -1/global batch sits in a buffer that captured chains read): the replayed
