@@ -310,6 +310,32 @@ def test_td3_device_replay_matches_host_gather():
             both_learn()
 
 
+def test_td3_learn_rows_host_and_device_rows_agree():
+    """learn_rows on a minibatch given as a numpy array, as a host tensor and as a device tensor (the block the update
+    fetches then holds noise and optimizer scalars only): bit-identical learners, with noise from the caller and with
+    noise drawn on the device, through the eager first updates and the replayed ones."""
+    import hhrl_vae_amd.algorithm as A
+    for with_noise in (True, False):
+        mk = lambda: A.HATD3Triple(gen.light_cfg(o=(5, 6, 7), T=4, s=8, a=(1, 2, 3), actor_h=(12, 10), critic_h=(14, 12),
+                                                 batch=8, cap=24), seed=9, device_replay=False)
+        nets = [mk(), mk(), mk()]
+        W, dims = nets[0].fam.row_width, nets[0].fam.a_dims
+        for it in range(12):
+            rs = np.random.RandomState(500 + it)
+            rows = rs.uniform(-1, 1, size=(8, W)).astype(np.float32)
+            noise = [rs.standard_normal((8, a)).astype(np.float32) for a in dims] if with_noise else None
+            forms = (rows, torch.from_numpy(rows), torch.from_numpy(rows).cuda())
+            for net, r in zip(nets, forms):
+                net.learn_rows(r, noise, list(range(len(dims))))
+        assert all(set(n.launch_forms().values()) == {"graph"} for n in nets)
+        ref = nets[0].state_dicts()
+        for other in nets[1:]:
+            sd = other.state_dicts()
+            for n in ref:
+                for k in ref[n]:
+                    assert torch.equal(ref[n][k], sd[n][k]), (with_noise, n, k)
+
+
 def test_td3_smoothing_noise_drawn_on_the_device():
     """Without noise from the caller a single-device learner draws the target-policy smoothing noise (algorithm.py:790,
     1333: torch.randn_like on the device) in the update's first launch: consecutive runs of the standard-normal stream
