@@ -556,9 +556,10 @@ class TD3Learner:
     class _Static:
         """Per-batch-size device buffers with fixed addresses (a captured graph replays on them).
 
-        Everything an update needs from the host -- the sampled rows, the smoothing noise, the scalars of
-        the Adam steps -- sits in ONE device block that is refreshed by ONE transfer from a ring of pinned
-        host buffers (a slot is reused only after the transfer that read it has completed)."""
+        Everything an update needs from the host -- the sampled rows or their row numbers, the smoothing noise
+        (or the seed and offset of its stream), the scalars of the Adam steps -- sits in ONE device block, refreshed
+        once per update from a pinned staging block of the update's launch chain (`_Ring`): by the update's first
+        launch where the block is small, by one transfer in front of the update otherwise."""
 
         def __init__(self, fam: Family, B: int, dev, n_opt: int):
             a64 = lambda n: (n + 63) & ~63
@@ -635,8 +636,14 @@ class TD3Learner:
 
         The kernel sequence of an update depends only on (B, policy step?, actor order); after two
         eager runs of a given combination it is captured into a HIP graph and replayed.  What changes
-        from update to update (rows, noise, the scalars of the Adam steps) reaches the device in one
-        transfer before the replay.
+        from update to update (rows, noise, the scalars of the Adam steps) sits in one pinned block that
+        the update's first launch fetches (small blocks; one graph per block) or one transfer brings over
+        before the replay.
+
+        noise: one [B, a] array per actor, the standard normals of the target-policy smoothing
+        (algorithm.py:790, 1333).  None: drawn here -- on the device, in the update's first launch, by a
+        single-device learner with graphs (the stream of hhrl_randn_fill for this learner's seed), else
+        from this learner's numpy generator.
 
         global_batch (data-parallel): rows of the global minibatch over all ranks, the divisor of the batch
         means (default: this rank's rows x world size, i.e. equal shards)."""
