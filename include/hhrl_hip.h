@@ -36,7 +36,10 @@ extern "C" {
 /* Library identification / diagnostics. */
 /* The ABI version this header describes; hhrl_version() returns the one the library was built with.  A binding checks
  * that they agree before it passes descriptor structs (their layout is part of the ABI).
- * 101: hhrl_lstm_desc gained `no_backward`; hhrl_gather_copy_group, hhrl_randn_fill, hhrl_vae_learn_steps added. */
+ * 101: hhrl_lstm_desc gained `no_backward`; hhrl_gather_copy_group, hhrl_randn_fill, hhrl_vae_learn_steps added.
+ * 102: hhrl_mlp3_backward_group_adam (hhrl_adam_ride), hhrl_td3_target_mse_zeroed added.
+ * 103: hhrl_mlp3_desc gained the mse_* fields; hhrl_mlp3_slab_floats is positive for every M (one more entry per row).
+ * 104: hhrl_gcopy_desc.gather gained 2 (flat copy) and 3 (standard normals); row numbers may lie in pinned memory. */
 #define HHRL_ABI_VERSION 104
 int hhrl_version(void);
 const char* hhrl_last_error(void);
