@@ -167,3 +167,29 @@ def test_off_policy_correction_matches_reference(impl):
     assert np.array_equal(got[:, 2], fx["fn/goals"][:, 2].astype(np.float64))       # all candidates tie -> stored goal kept
     if impl == "product":
         assert calls == [8 * 10 * 6 * 25]                        # every lane and candidate in one policy call
+
+
+def test_copy_queue_reads_a_fetched_block_in_place():
+    """ops.CopyQueue with a staging block that the same launch fetches: whatever a copy (or the row numbers of a
+    gather) would read out of the block's device copy is redirected to the pinned block, copies of gathered rows go to
+    the replay table, everything else is left alone; the fetch pieces come first, then the gather of the rows."""
+    from hhrl_vae_amd import ops
+    PIN, DEV, ROWS, TABLE, OUT = 0x10000, 0x90000, 0x50000, 0x200000, 0x700000
+    W = 36
+    fetch = ((PIN + 4 * 512, DEV + 4 * 512, 64), (PIN + 4 * 100, DEV + 4 * 100, 28))
+    q = ops.CopyQueue(8, gather=(ROWS, W, TABLE, 1000, DEV + 4 * 520), fetch=fetch)
+    assert q.items[:2] == [(PIN + 4 * 512, 0, DEV + 4 * 512, 0, 64, 2), (PIN + 4 * 100, 0, DEV + 4 * 100, 0, 28, 2)]
+    assert q.items[2] == (TABLE, W, ROWS, W, W, 1)
+    q.add(ROWS + 4 * 5, W, OUT, 12, 7)                   # a column range of the gathered rows: straight from the table
+    q.add(DEV + 4 * 110, 3, OUT + 64, 3, 3)              # inside the second fetched piece: from the pinned block
+    q.add(DEV + 4 * 300, 3, OUT + 128, 3, 3)             # in the device block but not fetched by this launch: as given
+    q.add(0x400000, 9, OUT + 256, 9, 9)                  # elsewhere: as given
+    q.add_zero(OUT + 512, 40)
+    q.add_normals(OUT + 1024, 16, PIN + 4 * 530)
+    assert q.items[3:] == [(TABLE + 4 * 5, W, OUT, 12, 7, 1), (PIN + 4 * 110, 3, OUT + 64, 3, 3, 0),
+                           (DEV + 4 * 300, 3, OUT + 128, 3, 3, 0), (0x400000, 9, OUT + 256, 9, 9, 0),
+                           (None, 0, OUT + 512, 0, 40, 0), (PIN + 4 * 530, 0, OUT + 1024, 0, 16, 3)]
+    assert q._pinned(DEV + 4 * 520) == PIN + 4 * 520 and q._pinned(DEV + 4 * 576) == DEV + 4 * 576      # row numbers; one past the piece
+    plain = ops.CopyQueue(8)
+    plain.add(DEV + 4 * 110, 3, OUT, 3, 3)
+    assert plain.items == [(DEV + 4 * 110, 3, OUT, 3, 3, 0)]
