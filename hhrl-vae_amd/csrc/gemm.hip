@@ -576,8 +576,14 @@ int gemm_group(const GemmArgs* gs, int n, hipStream_t st) {
   GemmGroup grp;
   grp.splits = 1;
   int chunk = 0;
-  if (reduce_mode && max_k > 1024) {
-    grp.splits = ceil_div(max_k, 512) < 8 ? ceil_div(max_k, 512) : 8;
+  // Weight gradients reduce over the batch rows: from 1024 rows on the reduction is dealt over workgroups in slices of
+  // 256 (float atomics combine them) -- a [300, 400] gradient is 130 tiles, half the CUs, each walking all 1024 rows of a
+  // batch-1024 update otherwise (HATD3Triple at batch 1024: 1166 -> 1121 us per update; slices of 512: 1127, of 128: 1172).
+  // HHRL_GEMM_SPLIT_CHUNK sets another slice length (sweeps).
+  static int split_chunk = 0;
+  if (split_chunk == 0) { const char* e = getenv("HHRL_GEMM_SPLIT_CHUNK"); split_chunk = (e && atoi(e) > 0) ? atoi(e) : 256; }
+  if (reduce_mode && max_k >= 1024) {
+    grp.splits = ceil_div(max_k, split_chunk) < 8 ? ceil_div(max_k, split_chunk) : 8;
     chunk = (ceil_div(max_k, grp.splits) + 7) & ~7;
     grp.splits = ceil_div(max_k, chunk);
   }
@@ -615,11 +621,13 @@ static int gemm_one(GemmArgs g, hipStream_t st) {
   const long tiles32 = (long)ceil_div(M, 32) * ceil_div(N, 32);
   if (tiles32 <= small_limit()) {
     int gz = 1;
-    if (mode == 2 && K > 1024) {
+    static int split_chunk = 0;
+    if (split_chunk == 0) { const char* e = getenv("HHRL_GEMM_SPLIT_CHUNK"); split_chunk = (e && atoi(e) > 0) ? atoi(e) : 256; }
+    if (mode == 2 && K >= 1024) {
       // weight gradients over many rows: spread the reduction over workgroups too (atomics combine)
       long want = 1024 / tiles32;
       if (want < 1) want = 1;
-      gz = (int)(ceil_div(K, 512) < want ? ceil_div(K, 512) : want);
+      gz = (int)(ceil_div(K, split_chunk) < want ? ceil_div(K, split_chunk) : want);
       int chunk = ceil_div(K, gz);
       chunk = (chunk + 7) & ~7;
       g.k_chunk = chunk;
