@@ -42,6 +42,7 @@ def main():
         d.obs, d.ldobs, d.o = obs.data_ptr(), T * o, o
         d.params = C.cast(parr, C.c_void_p)
         d.out, d.ldo, d.ws = od.data_ptr(), H, ws.data_ptr()
+        d.no_backward = 1 if os.environ.get("LSTM_NO_BACKWARD") == "1" else 0      # (forward stamps without the saved steps)
         keep.append((pd, parr, ws, od, obs))
     st = L.stream_ptr()
     for _ in range(5):
