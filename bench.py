@@ -466,6 +466,12 @@ def main() -> None:
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args, sys.argv[1:]))
 
+    # stdout carries the JSON line and nothing else: whatever a library prints there (RCCL announces its version on
+    # the first communicator) is sent to stderr, the line itself goes to the descriptor stdout had
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     wd = float(os.environ.get("HHRL_BENCH_WATCHDOG", "0"))
     if wd > 0:                      # diagnostic: a rank still running after that many seconds says where and exits
         import faulthandler
@@ -654,7 +660,8 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline:
             progress("CPU oracle: VAE step")
             out["cpu_baseline"] = cpu_baseline_vae(B, N, g)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if group is not None:
         import torch.distributed as dist
         dist.barrier()
