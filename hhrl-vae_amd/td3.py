@@ -553,6 +553,8 @@ class TD3Learner:
         raise NotImplementedError
 
     # ---- the update -------------------------------------------------------
+    FETCH_MAX_FLOATS = 1 << 21          # largest staging block an update fetches itself (first launch of its chain)
+
     class _Static:
         """Per-batch-size device buffers with fixed addresses (a captured graph replays on them).
 
@@ -695,7 +697,7 @@ class TD3Learner:
             h[:st.n_rows].reshape(B, W)[:] = rows.numpy() if isinstance(rows, torch.Tensor) else rows
         lo = st.n_rows if rows_on_device else 0             # rows already on the device: noise, scalars and row numbers only
         n_up = st.total - lo
-        in_body = (self.group is None and self.use_graph is True and ring.zero_copy and n_up <= _lib.ZERO_COPY_MAX_FLOATS)
+        in_body = self.group is None and self.use_graph is True and ring.zero_copy and n_up <= self.FETCH_MAX_FLOATS
         on_device = on_device and in_body
         for k, a in enumerate(fam.a_dims):
             if on_device:
@@ -719,7 +721,9 @@ class TD3Learner:
         # launch of the chain (the first node of its graph; one graph per block).  A transfer enqueued between two
         # replays costs the device 14 us per update (WorkerTD3 at batch 4096: 95.8 -> 82.0 us; the stream hands over to
         # the copy engine and back, or, with a copy kernel on the stream, from one replay to a plain dispatch and on to
-        # the next replay).  Large blocks (rows gathered on the host) keep the DMA transfer.
+        # the next replay).  That holds up to blocks of megabytes (rows gathered on the host: HATD3Triple at batch 64, 256,
+        # 1024 with 0.26, 1.0, 4.1 MB: 377 -> 361, 540 -> 524, 1213 -> 1200 us per update); beyond FETCH_MAX_FLOATS the
+        # DMA transfer stays.
         stream = _lib.current_stream()
         if in_body:
             hp, n0, n1 = ring.h_ptr[slot], st.noise_off[0], st.hyper_off[0]
