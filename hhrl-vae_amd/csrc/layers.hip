@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void gather_copy_group_kernel(GCopyGroup grp, 
   __shared__ int sidx[kGcMaxRows];
   const GCopyInst& g = grp.in[blockIdx.y];
   const int tid = threadIdx.x, C = g.C;
-  if (g.in == nullptr || g.gather >= 2) {             // flat: C floats, an equal run of whole 16-byte groups per workgroup
+  if (g.in == nullptr || g.gather == 2 || g.gather == 3) {   // flat: C floats, an equal run of whole 16-byte groups per workgroup
     const long quads = ((long)C + 3) / 4, per = (quads + gridDim.x - 1) / gridDim.x;
     const long lo = 4 * per * blockIdx.x, hi = lo + 4 * per < C ? lo + 4 * per : C;
     if (g.in == nullptr) {
@@ -251,6 +251,21 @@ __global__ __launch_bounds__(256) void gather_copy_group_kernel(GCopyGroup grp, 
     return;
   }
   const int R = gc_tile_rows(C), row0 = blockIdx.x * R;
+  if (g.gather == 4) {
+    // rows stored since the last update on their way into the device-resident replay buffer: in = {int count;
+    // int position[63]} followed, 64 floats on, by the rows [count][C]; row k goes to out[position[k]][0..C).  Count and
+    // positions are read from memory, so a replayed launch scatters what the caller has put there (possibly nothing).
+    const int* hdr = reinterpret_cast<const int*>(g.in);
+    const int n_new = min(hdr[0], 63);
+    if (row0 >= n_new) return;
+    const float* rows = g.in + 64;
+    const int n = min(R, n_new - row0) * C;
+    for (int e = tid; e < n; e += 256) {
+      const int rr = e / C, c = e - rr * C;
+      g.out[(long)min(max(hdr[1 + row0 + rr], 0), n_in - 1) * g.ldo + c] = rows[(long)(row0 + rr) * C + c];
+    }
+    return;
+  }
   if (row0 >= M) return;
   if (g.gather) {
     if (tid < R && row0 + tid < M) sidx[tid] = min(max(idx[row0 + tid], 0), n_in - 1);   // an index outside the buffer cannot leave it
@@ -567,11 +582,16 @@ int hhrl_gather_copy_group(const hhrl_gcopy_desc* d, int n, int M, const int* id
   for (int i = 0; i < n; ++i) {
     HHRL_REQUIRE(d[i].out, "gather_copy_group: block %d: null pointer", i);
     HHRL_REQUIRE(d[i].C > 0, "gather_copy_group: block %d: C=%d", i, d[i].C);
-    HHRL_REQUIRE(d[i].gather >= 0 && d[i].gather <= 3, "gather_copy_group: block %d: gather=%d", i, d[i].gather);
+    HHRL_REQUIRE(d[i].gather >= 0 && d[i].gather <= 4, "gather_copy_group: block %d: gather=%d", i, d[i].gather);
+    HHRL_REQUIRE(d[i].gather != 4 || (d[i].in && n_in > 0 && d[i].ldo >= d[i].C),
+                 "gather_copy_group: block %d scatters rows, but there is no source, no table size or ldo < C", i);
     HHRL_REQUIRE(d[i].gather != 3 || (d[i].in && reinterpret_cast<uintptr_t>(d[i].in) % 8 == 0),
                  "gather_copy_group: block %d: the seed and offset of a block of normals must be 8-byte aligned", i);
     long need;
-    if (d[i].in && d[i].gather < 2) {
+    if (d[i].in && d[i].gather == 4) {
+      need = ceil_div(63, gc_tile_rows(d[i].C));
+      bytes += 8.0 * 63 * d[i].C;
+    } else if (d[i].in && d[i].gather < 2) {
       HHRL_REQUIRE(d[i].ldi >= d[i].C && d[i].ldo >= d[i].C, "gather_copy_group: block %d: bad shape C=%d ldi=%ld ldo=%d", i, d[i].C,
                    d[i].ldi, d[i].ldo);
       HHRL_REQUIRE(!d[i].gather || (idx && n_in > 0), "gather_copy_group: block %d gathers, but there are no row numbers", i);

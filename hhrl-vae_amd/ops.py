@@ -277,6 +277,11 @@ class CopyQueue:
         integers at address `seed_offset` (read by the launch itself: a replay draws what the caller has put there)."""
         self.items.append((seed_offset, 0, out, 0, n, 3))
 
+    def add_scatter(self, src: int, table: int, ld: int, Cc: int) -> None:
+        """Rows on their way into a device-resident table [n_table_rows][ld] (gather mode): `src` points at
+        {int32 count <= 63; int32 position[63]} and, 64 floats on, the rows [count][Cc]; read by the launch itself."""
+        self.items.append((src, 0, table, ld, Cc, 4))
+
     def add_zero(self, out: int, n: int) -> None:
         """n floats at `out` set to zero in the same launch (a gradient buffer's zero_grad)."""
         self.items.append((None, 0, out, 0, n, 0))

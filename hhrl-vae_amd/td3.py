@@ -590,20 +590,25 @@ class TD3Learner:
             self.pi = [ops.dev_empty(B, a, device=dev) for a in fam.a_dims]
             self.y = ops.dev_empty(B, 1, device=dev)
 
-        def ring(self, key: tuple) -> "TD3Learner._Ring":
+        def ring(self, key: tuple, row_width: int = 0) -> "TD3Learner._Ring":
+            """row_width > 0: the blocks have room for rows on their way into a device-resident replay buffer."""
             r = self.rings.get(key)
             if r is None:
-                r = self.rings[key] = TD3Learner._Ring(self)
+                r = self.rings[key] = TD3Learner._Ring(self, row_width)
             return r
 
     class _Ring:
         """The pinned staging blocks of ONE launch chain: the host fills one while the device reads the other.  A chain
         has blocks of its own because its captured graph names them: the graph's first node fetches the block."""
         SLOTS = 2
+        NEW_ROWS_MAX = 16         # replay rows stored since the last update that may ride in the block (<= 63)
 
-        def __init__(self, st: "TD3Learner._Static"):
+        def __init__(self, st: "TD3Learner._Static", row_width: int = 0):
             B = st.B
-            self.h_in = [torch.zeros(st.total, dtype=torch.float32).pin_memory() for _ in range(self.SLOTS)]
+            # behind the part that mirrors the device block: {count, positions} and the rows themselves
+            self.new_off = st.total
+            extra = 64 + self.NEW_ROWS_MAX * row_width if row_width else 0
+            self.h_in = [torch.zeros(st.total + extra, dtype=torch.float32).pin_memory() for _ in range(self.SLOTS)]
             self.h_np = [t.numpy() for t in self.h_in]
             self.h_ptr = [t.data_ptr() for t in self.h_in]
             self.h_idx = [t[st.idx_off:st.idx_off + B].view(torch.int32).numpy() for t in self.h_in]
@@ -613,6 +618,9 @@ class TD3Learner:
             # the spare part of the first optimizer's scalars
             self.rng_off = st.hyper_off[0] + 16
             self.h_rng = [h[self.rng_off:self.rng_off + 4].view(np.uint64) for h in self.h_np]
+            if row_width:
+                self.h_new_hdr = [h[self.new_off:self.new_off + 64].view(np.int32) for h in self.h_np]
+                self.h_new_rows = [h[self.new_off + 64:].reshape(self.NEW_ROWS_MAX, row_width) for h in self.h_np]
             self.zero_copy = all(_lib.zero_copy_ok(t, any_size=True) for t in self.h_in)      # kernels may read the blocks in place
             self.events: List[Optional["torch.cuda.Event"]] = [None] * self.SLOTS
             self.turn = 0
@@ -632,9 +640,11 @@ class TD3Learner:
             ev.record(stream)
 
     def learn_rows(self, rows, noise: Optional[Sequence] = None, order: Optional[Sequence[int]] = None,
-                   _indices=None, global_batch: Optional[int] = None) -> None:
+                   _indices=None, global_batch: Optional[int] = None, _new_rows=None) -> None:
         """One TD3 update on a [B, row_width] block of replay rows (numpy array, host or device tensor).
-        _indices (device replay, rows=None): the B row numbers to gather from the device mirror instead.
+        _indices (device replay, rows=None): the B row numbers to gather from the device mirror instead;
+        _new_rows: positions of rows stored since the last update that are not in the mirror yet (none of them among
+        _indices): they travel with this update where its first launch fetches the staging block, else by _sync_replay().
 
         The kernel sequence of an update depends only on (B, policy step?, actor order); after two
         eager runs of a given combination it is captured into a HIP graph and replayed.  What changes
@@ -687,7 +697,7 @@ class TD3Learner:
         # the stream of hhrl_randn_fill for this learner's seed.  4096 draws cost the host 26 us per update otherwise.
         on_device = noise is None and self.group is None and self.use_graph is True
         key = (B, policy, order, gather, global_batch, on_device)
-        ring = st.ring(key)
+        ring = st.ring(key, W if gather else 0)
         slot = ring.next_slot()
         h = ring.h_np[slot]
         rows_on_device = gather or (isinstance(rows, torch.Tensor) and rows.is_cuda)
@@ -725,6 +735,18 @@ class TD3Learner:
         # 1024 with 0.26, 1.0, 4.1 MB: 377 -> 361, 540 -> 524, 1213 -> 1200 us per update); beyond FETCH_MAX_FLOATS the
         # DMA transfer stays.
         stream = _lib.current_stream()
+        scatter = None
+        if gather and in_body:
+            hdr = ring.h_new_hdr[slot]
+            n_new = 0 if _new_rows is None else len(_new_rows)
+            hdr[0] = n_new
+            if n_new:
+                hdr[1:1 + n_new] = _new_rows
+                ring.h_new_rows[slot][:n_new] = self.memory[_new_rows]
+                self._synced = self.pointer
+            scatter = ring.h_ptr[slot] + 4 * ring.new_off
+        elif _new_rows is not None:
+            self._sync_replay()
         if in_body:
             hp, n0, n1 = ring.h_ptr[slot], st.noise_off[0], st.hyper_off[0]
             if on_device:                                   # everything but the noise, which the launch draws itself
@@ -733,12 +755,12 @@ class TD3Learner:
                 pieces = ((hp + 4 * n1, P(st.d_in, n1), st.total - n1),)
                 if lo < n0:
                     pieces += ((hp + 4 * lo, P(st.d_in, lo), n0 - lo),)
-                st.upload = (pieces, slot, (P(st.d_in, n0), n1 - n0, hp + 4 * ring.rng_off))
+                st.upload = (pieces, slot, (P(st.d_in, n0), n1 - n0, hp + 4 * ring.rng_off), scatter)
             else:
-                st.upload = (((hp + 4 * lo, P(st.d_in, lo), n_up),), slot, None)
+                st.upload = (((hp + 4 * lo, P(st.d_in, lo), n_up),), slot, None, scatter)
         else:
             st.upload = None
-            st.d_in[lo:].copy_(ring.h_in[slot][lo:], non_blocking=True)
+            st.d_in[lo:].copy_(ring.h_in[slot][lo:st.total], non_blocking=True)
             ring.release_after(slot, stream)
         st.gather = gather                                  # the update starts by gathering its rows on the device
         st.global_batch = global_batch
@@ -936,6 +958,8 @@ class TD3Learner:
                            fetch=st.upload[0] if st.upload is not None else None)
         if st.upload is not None and st.upload[2] is not None:
             cq.add_normals(*st.upload[2])                # the smoothing noise of every actor, one run of the stream
+        if st.upload is not None and st.upload[3] is not None:
+            cq.add_scatter(st.upload[3], P(self._dev_mem), W, W)     # rows stored since the last update, into the mirror
         for k, a in enumerate(self.actor_targets):
             a.stage_inputs(cq, B, next_obs[k][0], W, next_goal, W)
         ct.stage_inputs(cq, B, next_obs, next_goal, W)
@@ -1090,8 +1114,20 @@ class TD3Learner:
             # randint(0, n, size=B) -- same values, same generator state afterwards -- without 2 us of argument checks
             indices = np.random.randint(0, min(self._n_stored(), self.memory_capacity), size=self.batch_size)
         if self.device_replay and hasattr(self, "_sync_replay"):
-            self._sync_replay()
-            self.learn_rows(None, noise, order, _indices=np.asarray(indices), global_batch=global_batch)
+            # Rows stored since the last update (one per control step, typically) ride in the update's staging block
+            # instead of a transfer of their own in front of it -- unless this minibatch samples one of them (the gather
+            # and the scatter share a launch), or there are many (bulk fills, mark_replay_dirty()).
+            indices = np.asarray(indices)
+            cap = self.memory_capacity
+            new = min(self.pointer - self._synced, cap)
+            ride = None
+            if 0 < new <= TD3Learner._Ring.NEW_ROWS_MAX and self.group is None and self.use_graph is True:
+                first = (self.pointer - new) % cap
+                if not ((indices - first) % cap < new).any():
+                    ride = (first + np.arange(new)) % cap
+            if ride is None:
+                self._sync_replay()
+            self.learn_rows(None, noise, order, _indices=indices, global_batch=global_batch, _new_rows=ride)
         else:
             self.learn_rows(self._sample_rows(np.asarray(indices)), noise, order, global_batch=global_batch)
 

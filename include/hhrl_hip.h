@@ -39,7 +39,8 @@ extern "C" {
  * 101: hhrl_lstm_desc gained `no_backward`; hhrl_gather_copy_group, hhrl_randn_fill, hhrl_vae_learn_steps added.
  * 102: hhrl_mlp3_backward_group_adam (hhrl_adam_ride), hhrl_td3_target_mse_zeroed added.
  * 103: hhrl_mlp3_desc gained the mse_* fields; hhrl_mlp3_slab_floats is positive for every M (one more entry per row).
- * 104: hhrl_gcopy_desc.gather gained 2 (flat copy) and 3 (standard normals); row numbers may lie in pinned memory. */
+ * 104: hhrl_gcopy_desc.gather gained 2 (flat copy), 3 (standard normals) and 4 (scattered rows); row numbers may lie in
+ *      pinned memory. */
 #define HHRL_ABI_VERSION 104
 int hhrl_version(void);
 const char* hhrl_last_error(void);
@@ -143,8 +144,12 @@ int hhrl_gather_rows(const float* in, long ldi, int n_in, const int* idx, float*
  * block on its way into device memory in the same launch.  gather == 3: out[0..C) = elements offset .. offset + C - 1
  * of the standard-normal stream of hhrl_randn_fill, where `in` points at two 64-bit integers {seed, offset} (offset a
  * multiple of four) that the launch reads from memory: the draws of `torch.randn_like` for the target-policy smoothing
- * (algorithm.py:790, 1333) inside a replayed launch.  `idx` and the sources may lie in pinned host memory that the
- * device can address: the row numbers are read once per tile of rows. */
+ * (algorithm.py:790, 1333) inside a replayed launch.  gather == 4: rows stored since the last update
+ * (`store_transition`, algorithm.py:273, 465, 750, 1299) on their way into the device-resident replay buffer `out`
+ * ([n_in][ldo]): `in` points at {int count (<= 63); int position[63]} and, 64 floats further, the rows [count][C];
+ * row k goes to out[position[k]].  The caller sees to it that no block of the launch gathers one of these positions.
+ * `idx` and the sources may lie in pinned host memory that the device can address: the row numbers are read once per
+ * tile of rows. */
 typedef struct { const float* in; long ldi; float* out; int ldo; int C; int gather; } hhrl_gcopy_desc;
 int hhrl_gather_copy_group(const hhrl_gcopy_desc* blocks, int n, int M, const int* idx, int n_in, void* stream);
 /* p[i] = value */

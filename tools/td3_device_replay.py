@@ -16,15 +16,18 @@ for name, mk, n in (("worker", lambda dr: WorkerTD3(gen.cav_cfg(cap=4096), devic
     for dr in (False, True):
         net = mk(dr)
         net.memory[:n] = np.random.RandomState(1).uniform(0, 1, size=(n, net.fam.row_width)); net.pointer = n
-        for it in range(500):
+        for it in range(2000):                      # until every launch chain is replayed from its graphs
             net.learn() if name == "worker" else net.learn(None)
             f = net.launch_forms()
-            if it >= 30 and len(f) == (2 if name == "worker" else 7): break
+            if it >= 30 and len(f) == (2 if name == "worker" else 7) and "tuning" not in f.values(): break
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < 0.5:      # ... and the device has been busy for half a second
+            net.learn() if name == "worker" else net.learn(None)
         torch.cuda.synchronize()
         row = np.random.RandomState(2).uniform(0, 1, size=net.fam.row_width)
         t0 = time.perf_counter()
-        for _ in range(200):
+        for _ in range(1000):
             net._store(row)                         # one new transition per update, as in the control loop
             net.learn() if name == "worker" else net.learn(None)
         torch.cuda.synchronize()
-        print(name, "device_replay", dr, "ms/update %.4f" % (1e3 * (time.perf_counter() - t0) / 200))
+        print(name, "device_replay", dr, "ms/update %.4f" % (1e3 * (time.perf_counter() - t0) / 1000))

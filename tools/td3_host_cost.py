@@ -23,7 +23,7 @@ for name, net, n in (("worker", WorkerTD3(gen.cav_cfg(cap=120000)), 120000), ("t
     st = net._statics[net.batch_size]
     ring = next(iter(st.rings.values()))
     t0 = time.perf_counter()
-    for _ in range(K): st.d_in.copy_(ring.h_in[0], non_blocking=True)
+    for _ in range(K): st.d_in.copy_(ring.h_in[0][:st.total], non_blocking=True)
     torch.cuda.synchronize()
     h2d = (time.perf_counter() - t0) / K
     rows_d = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32)).cuda()
